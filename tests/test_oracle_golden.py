@@ -1,0 +1,101 @@
+"""The CPU oracle against vectors produced by the reference itself (oracle/gen_golden.py).
+
+Bit-exact everywhere the oracle calls the same torch CPU ops as the reference.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_names, load_golden
+from oracle import gptq_oracle as O
+
+
+def test_g1_add_batch_bit_exact():
+    g = load_golden("g1_add_batch")
+    C = g["X"].shape[-1]
+    H = torch.zeros(C, C)
+    n = 0
+    for k in range(g["X"].shape[0]):
+        n = O.hessian_add_batch(H, n, torch.from_numpy(g["X"][k]))
+        assert np.array_equal(H.numpy(), g["H_after"][k])
+    assert n == int(g["nsamples"])
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4, 8])
+@pytest.mark.parametrize("sym", [False, True])
+def test_g2_find_params_quantize_bit_exact(bits, sym):
+    g = load_golden("g2_find_params")
+    W = torch.from_numpy(g["W"])
+    tag = f"b{bits}_{'sym' if sym else 'asym'}"
+    s, z = O.find_params(W, 2 ** bits - 1, sym)
+    assert np.array_equal(s.numpy(), g[tag + "_scale"])
+    assert np.array_equal(z.numpy(), g[tag + "_zero"])
+    q = O.quantize(W, s, z, 2 ** bits - 1)
+    assert np.array_equal(q.numpy(), g[tag + "_q"])
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names("g3_") if n != "g3_mid512"])
+def test_g3_fasterquant_bit_exact(name):
+    g = load_golden(name)
+    r = O.fasterquant(
+        torch.from_numpy(g["W"]), torch.from_numpy(g["H"]), bits=int(g["bits"]), sym=bool(g["sym"]),
+        blocksize=int(g["blocksize"]), percdamp=float(g["percdamp"]), groupsize=int(g["groupsize"]),
+        actorder=bool(g["actorder"]), static_groups=bool(g["static_groups"]))
+    assert np.array_equal(r.Hinv.numpy(), g["Hinv"])
+    assert np.array_equal(r.Q.numpy(), g["Q"])
+    assert np.array_equal(r.scale.numpy(), g["scale"])
+    assert np.array_equal(r.zero.numpy(), g["zero"])
+    assert r.error == float(g["error"])
+
+
+def test_g3_mid512_bit_exact():
+    g = load_golden("g3_mid512")
+    C = g["W"].shape[1]
+    H = torch.zeros(C, C)
+    n = 0
+    for k in range(g["X"].shape[0]):
+        n = O.hessian_add_batch(H, n, torch.from_numpy(g["X"][k]))
+    assert np.array_equal(H.numpy(), g["H"])
+    r = O.fasterquant(torch.from_numpy(g["W"]), H, bits=4, sym=False)
+    assert np.array_equal(r.codes.numpy().astype(np.uint8), g["codes"])
+    assert np.array_equal(r.Q.numpy(), g["Q"])
+    assert r.error == float(g["error"])
+
+
+@pytest.mark.parametrize("bits", [3, 4])
+def test_g4_pack_bit_exact(bits):
+    g = load_golden("g4_pack")
+    tag = f"b{bits}_"
+    iw = O.intweight(torch.from_numpy(g[tag + "W"]), torch.from_numpy(g[tag + "scale"]),
+                     torch.from_numpy(g[tag + "zero"]))
+    qw = (O.pack3 if bits == 3 else O.pack4)(iw)
+    assert qw.dtype == np.int32
+    assert np.array_equal(qw, g[tag + "qweight"])
+    back = (O.unpack3 if bits == 3 else O.unpack4)(qw)
+    assert np.array_equal(back, iw)
+
+
+def test_pack3_wraparound_matches_uint32_semantics():
+    # out-of-range codes bleed into neighbours exactly like numpy uint32 |= << (quant.py:166-183)
+    rng = np.random.default_rng(0)
+    iw = rng.integers(0, 2 ** 32, size=(64, 5), dtype=np.uint64).astype(np.uint32)
+    qw = O.pack3(iw).astype(np.uint32)
+    blk = iw[:32]
+    w0 = np.zeros(5, np.uint32)
+    for j in range(10):
+        w0 |= blk[j] << np.uint32(3 * j)
+    w0 |= blk[10] << np.uint32(30)
+    assert np.array_equal(qw[0], w0)
+
+
+def test_dequant_matvec_formula():
+    g = load_golden("g4_pack")
+    for bits in (3, 4):
+        tag = f"b{bits}_"
+        W = g[tag + "W"].astype(np.float64)          # already on the grid
+        x = np.linspace(-1, 1, W.shape[1])
+        y = O.dequant_matvec(x, g[tag + "qweight"], g[tag + "bias"], g[tag + "scales_buf"],
+                             g[tag + "zeros_buf"], bits)
+        ref = g[tag + "bias"].astype(np.float64) + W @ x
+        # W is the fp16-rounded grid value; the packed form is the exact grid
+        assert np.allclose(y, ref, rtol=0, atol=2e-3 * np.abs(W).max() * W.shape[1] ** 0.5)
