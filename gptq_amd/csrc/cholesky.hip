@@ -1,0 +1,261 @@
+// Damped inverse factor  U (upper, U^T U = (H + damp I)^-1)  -- replaces gptq.py:174-180.
+//
+// The reference runs three LAPACK factorizations (cholesky, cholesky_inverse,
+// cholesky(upper)), ~4/3 C^3 flop.  Here U is obtained in 2/3 C^3:
+//   Abar = J (H + damp I) J        (J = index reversal; padded to a multiple of 128 with I)
+//   Abar = L L^T                   (blocked right-looking Cholesky, fp32 MFMA trailing updates)
+//   => H + damp I = R R^T with R = J L J upper triangular, hence (H + damp I)^-1 = R^-T R^-1
+//   U = R^-1 = J L^-1 J            (L^-1 by recursive doubling: log2(C/128) levels of batched GEMMs)
+// All arithmetic is IEEE fp32 (no TF32/bf16), like gptq.py:18-19.
+#include "gemm_f32.h"
+
+namespace gptq {
+
+constexpr int NB = 128;   // Cholesky block size == GEMM tile size
+
+// ---------------------------------------------------------------------------------------------
+// damp = percdamp * mean(diag(H))   (gptq.py:174), one workgroup.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void diag_mean_kernel(const float* __restrict__ H, int ldh, int C,
+                                                        float percdamp, float* __restrict__ damp,
+                                                        int32_t* __restrict__ info) {
+  __shared__ double part[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < C; i += 256) s += (double)H[(long)i * ldh + i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    *damp = percdamp * (float)(part[0] / (double)C);
+    if (info) *info = 0;
+  }
+}
+
+// Abar[i][j] = Hd[p(C-1-i)][p(C-1-j)] + (i == j) * damp for i, j < C; identity in the padding.
+// Only the upper triangle of H is read (H is symmetric; add_batch maintains the upper half).
+__global__ __launch_bounds__(256) void build_abar_kernel(const float* __restrict__ H, int ldh, int C,
+                                                         int Cp, const int32_t* __restrict__ perm,
+                                                         const float* __restrict__ damp,
+                                                         float* __restrict__ A) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.y;
+  if (j >= Cp || j > i) return;   // lower triangle of Abar only
+  float v;
+  if (i < C) {
+    int pi = C - 1 - i, pj = C - 1 - j;
+    if (perm) { pi = perm[pi]; pj = perm[pj]; }
+    const int lo = min(pi, pj), hi = max(pi, pj);
+    v = H[(long)lo * ldh + hi];
+    if (i == j) v += *damp;
+  } else {
+    v = (i == j) ? 1.f : 0.f;
+  }
+  A[(long)i * Cp + j] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Diagonal block: L_kk = chol(A_kk) in LDS, then X = L_kk^-1 written to the diagonal block of Linv.
+// 512 threads.  Factorization: right-looking, two barriers per column.  Inverse: column-parallel
+// forward substitution, a quad of lanes per column (rows i = 4r + q), DPP quad broadcast, no barriers.
+// ---------------------------------------------------------------------------------------------
+template <int Q>
+__device__ __forceinline__ float quad_bcast(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), Q * 0x55, 0xf, 0xf, true));
+}
+
+__global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__ A, float* __restrict__ Linv,
+                                                             int Cp, int kb, int32_t* __restrict__ info) {
+  constexpr int LD = NB + 1;
+  __shared__ float S[NB * LD];
+  __shared__ float rdiag[NB];
+  __shared__ float ddiag[NB];
+  const int tid = threadIdx.x;
+  float* Ak = A + (long)kb * NB * Cp + (long)kb * NB;
+
+  for (int idx = tid; idx < NB * NB; idx += 512) {
+    const int i = idx >> 7, k = idx & 127;
+    S[i * LD + k] = (k <= i) ? Ak[(long)i * Cp + k] : 0.f;
+  }
+  const int kx = tid & 31, iy = tid >> 5;
+  for (int j = 0; j < NB; ++j) {
+    __syncthreads();
+    // S[j][j] keeps the pivot a_jj (its square root goes to ddiag) so that every thread can
+    // read it here without a third barrier per column.
+    const float ajj = S[j * LD + j];
+    const float d = sqrtf(ajj);
+    if (tid > j && tid < NB) S[tid * LD + j] = S[tid * LD + j] / d;
+    if (tid == j) {
+      ddiag[j] = d;
+      rdiag[j] = 1.f / d;
+      if (!(ajj > 0.f) && info) atomicCAS(info, 0, kb * NB + j + 1);
+    }
+    __syncthreads();
+    for (int i = j + 1 + iy; i < NB; i += 16) {
+      const float li = S[i * LD + j];
+      for (int k = j + 1 + kx; k <= i; k += 32) S[i * LD + k] -= li * S[k * LD + j];
+    }
+  }
+  __syncthreads();
+  // write L_kk back (kept for inspection; later stages only use the inverse and the panels)
+  for (int idx = tid; idx < NB * NB; idx += 512) {
+    const int i = idx >> 7, k = idx & 127;
+    if (k <= i) Ak[(long)i * Cp + k] = (k == i) ? ddiag[i] : S[i * LD + k];
+  }
+
+  // ---- inverse: thread (c = tid >> 2, q = tid & 3) owns rows i = 4r + q of column c ----
+  const int c = tid >> 2, q = tid & 3;
+  float x[32];
+#pragma unroll
+  for (int r = 0; r < 32; ++r) x[r] = (4 * r + q == c) ? 1.f : 0.f;
+  const int c0 = (tid & ~63) >> 2;   // first column handled by this wave
+#pragma unroll
+  for (int jj = 0; jj < 32; ++jj) {
+    if (jj < (c0 >> 2)) continue;    // wave-uniform: rows above every column of the wave are zero
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      const int j = 4 * jj + qq;
+      const float xr = (qq == 0) ? quad_bcast<0>(x[jj]) : (qq == 1) ? quad_bcast<1>(x[jj])
+                     : (qq == 2) ? quad_bcast<2>(x[jj]) : quad_bcast<3>(x[jj]);
+      const float xj = xr * rdiag[j];
+      if (q == qq) x[jj] = xj;
+#pragma unroll
+      for (int r = jj; r < 32; ++r) {
+        const int i = 4 * r + q;
+        if (i > j) x[r] -= S[i * LD + j] * xj;
+      }
+    }
+  }
+  float* Xk = Linv + (long)kb * NB * Cp + (long)kb * NB;
+#pragma unroll
+  for (int r = 0; r < 32; ++r) {
+    const int i = 4 * r + q;
+    Xk[(long)i * Cp + c] = (i >= c) ? x[r] : 0.f;
+  }
+}
+
+// Panel:  P <- P * inv(L_kk)^T  for the block column kb below the diagonal (rows (kb+1)*128 ...).
+__global__ __launch_bounds__(GEMM_THREADS) void panel_kernel(float* __restrict__ A,
+                                                             const float* __restrict__ Linv, int Cp, int kb) {
+  __shared__ __attribute__((aligned(16))) float smem[GEMM_LDS_FLOATS];
+  const int tm = kb + 1 + blockIdx.x;
+  float* P = A + (long)tm * NB * Cp + (long)kb * NB;
+  const float* D = Linv + (long)kb * NB * Cp + (long)kb * NB;
+  Operand<float> a{P, Cp, 1, NB, true};
+  Operand<float> b{D, Cp, 1, NB, true};
+  gemm_tile<float, float, true, true>(a, b, 0, NB, smem,
+                                      [=](int r, int c, float v) { P[(long)r * Cp + c] = v; });
+}
+
+// Trailing update:  A[m][n] -= sum_k P[m][k] P[n][k]  on the lower tiles of the remaining matrix.
+__global__ __launch_bounds__(GEMM_THREADS) void syrk_kernel(float* __restrict__ A, int Cp, int kb, int nrem) {
+  __shared__ __attribute__((aligned(16))) float smem[GEMM_LDS_FLOATS];
+  int rest = blockIdx.x, tn = 0;           // column tile tn, row tile tm >= tn
+  while (rest >= nrem - tn) { rest -= nrem - tn; ++tn; }
+  const int tm = tn + rest;
+  const long r0 = (long)(kb + 1 + tm) * NB, c0 = (long)(kb + 1 + tn) * NB;
+  Operand<float> a{A + r0 * Cp + (long)kb * NB, Cp, 1, NB, true};
+  Operand<float> b{A + c0 * Cp + (long)kb * NB, Cp, 1, NB, true};
+  float* Ct = A + r0 * Cp + c0;
+  const bool diag = tm == tn;
+  gemm_tile<float, float, true, true>(a, b, 0, NB, smem, [=](int r, int c, float v) {
+    if (diag && c > r) return;
+    Ct[(long)r * Cp + c] -= v;
+  });
+}
+
+// Recursive-doubling inverse, level with segment size s (in 128-blocks).  For every pair
+// (A = blocks [2ps, 2ps+s), Cc = blocks [2ps+s, 2ps+2s) clipped) the off-diagonal block of the
+// inverse is X = -Cc^-1 * B * A^-1 with B = L[Cc, A].
+//   step 1:  T = B * A^-1, stored TRANSPOSED in the (unused) upper triangle of Linv;
+//   step 2:  X = -Cc^-1 * T  into the lower triangle of Linv.
+__global__ __launch_bounds__(GEMM_THREADS) void trtri_step1_kernel(const float* __restrict__ L,
+                                                                   float* __restrict__ Linv, int Cp,
+                                                                   int nblk, int s) {
+  __shared__ __attribute__((aligned(16))) float smem[GEMM_LDS_FLOATS];
+  const int p = blockIdx.y, ti = blockIdx.x / s, tj = blockIdx.x % s;
+  const int a0 = 2 * p * s, cb0 = a0 + s;
+  if (cb0 + ti >= nblk) return;
+  const long rm = (long)(cb0 + ti) * NB, cn = (long)(a0 + tj) * NB, ka = (long)a0 * NB;
+  Operand<float> a{L + rm * Cp + ka, Cp, 1, NB, true};            // B[m][k]
+  Operand<float> b{Linv + ka * Cp + cn, 1, Cp, NB, true};         // Ainv[k][n], lower: k >= n
+  float* Tt = Linv + cn * Cp + rm;                                // T^T lives at [n][m]
+  gemm_tile<float, float, true, false>(a, b, tj * NB, s * NB, smem,
+                                       [=](int r, int c, float v) { Tt[(long)c * Cp + r] = v; });
+}
+
+__global__ __launch_bounds__(GEMM_THREADS) void trtri_step2_kernel(float* __restrict__ Linv, int Cp,
+                                                                   int nblk, int s) {
+  __shared__ __attribute__((aligned(16))) float smem[GEMM_LDS_FLOATS];
+  const int p = blockIdx.y, ti = blockIdx.x / s, tj = blockIdx.x % s;
+  const int a0 = 2 * p * s, cb0 = a0 + s;
+  if (cb0 + ti >= nblk) return;
+  const long rm = (long)(cb0 + ti) * NB, cn = (long)(a0 + tj) * NB, kc = (long)cb0 * NB;
+  Operand<float> a{Linv + rm * Cp + kc, Cp, 1, NB, true};         // Cinv[m][k], lower: k <= m
+  Operand<float> b{Linv + cn * Cp + kc, Cp, 1, NB, true};         // T[k][n] read from T^T[n][k]
+  float* X = Linv + rm * Cp + cn;
+  gemm_tile<float, float, true, true>(a, b, 0, (ti + 1) * NB, smem,
+                                      [=](int r, int c, float v) { X[(long)r * Cp + c] = -v; });
+}
+
+// U[i][j] = Linv[C-1-i][C-1-j] for j >= i, zero below the diagonal.
+__global__ __launch_bounds__(256) void flip_to_upper_kernel(const float* __restrict__ Linv, int Cp, int C,
+                                                            float* __restrict__ U, int ldu) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.y;
+  if (j >= C) return;
+  U[(long)i * ldu + j] = (j >= i) ? Linv[(long)(C - 1 - i) * Cp + (C - 1 - j)] : 0.f;
+}
+
+}  // namespace gptq
+
+using namespace gptq;
+
+static inline int padded(int C) { return cdiv(C, NB) * NB; }
+
+extern "C" size_t gptq_hinv_workspace_bytes(int C) {
+  if (C <= 0) return 0;
+  const size_t Cp = padded(C);
+  Carver cv(nullptr);
+  cv.take<float>(Cp * Cp);   // Abar / L
+  cv.take<float>(Cp * Cp);   // Linv (+ T^T in its upper triangle)
+  cv.take<float>(64);        // damp
+  return cv.used();
+}
+
+extern "C" int gptq_hinv_upper(float* H, int ldh, int C, float percdamp, const int32_t* perm,
+                               int32_t* info, void* workspace, size_t workspace_bytes,
+                               gptq_stream_t stream) {
+  GPTQ_CHECK_ARG(H && workspace, "gptq_hinv_upper: null pointer");
+  GPTQ_CHECK_ARG(C > 0 && ldh >= C, "gptq_hinv_upper: bad sizes");
+  GPTQ_CHECK_ARG(workspace_bytes >= gptq_hinv_workspace_bytes(C), "gptq_hinv_upper: workspace too small");
+  GPTQ_CHECK_ARG(reinterpret_cast<uintptr_t>(workspace) % 256 == 0, "gptq_hinv_upper: workspace must be 256-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int Cp = padded(C), nblk = Cp / NB;
+  Carver cv(workspace);
+  float* A = cv.take<float>((size_t)Cp * Cp);
+  float* Linv = cv.take<float>((size_t)Cp * Cp);
+  float* damp = cv.take<float>(64);
+
+  diag_mean_kernel<<<1, 256, 0, s>>>(H, ldh, C, percdamp, damp, info);
+  build_abar_kernel<<<dim3(cdiv(Cp, 256), Cp), 256, 0, s>>>(H, ldh, C, Cp, perm, damp, A);
+  for (int kb = 0; kb < nblk; ++kb) {
+    potrf_inv_diag_kernel<<<1, 512, 0, s>>>(A, Linv, Cp, kb, info);
+    const int nrem = nblk - kb - 1;
+    if (nrem > 0) {
+      panel_kernel<<<nrem, GEMM_THREADS, 0, s>>>(A, Linv, Cp, kb);
+      syrk_kernel<<<nrem * (nrem + 1) / 2, GEMM_THREADS, 0, s>>>(A, Cp, kb, nrem);
+    }
+  }
+  for (int sz = 1; sz < nblk; sz *= 2) {
+    const int pairs = cdiv(nblk, 2 * sz);
+    trtri_step1_kernel<<<dim3(sz * sz, pairs), GEMM_THREADS, 0, s>>>(A, Linv, Cp, nblk, sz);
+    trtri_step2_kernel<<<dim3(sz * sz, pairs), GEMM_THREADS, 0, s>>>(Linv, Cp, nblk, sz);
+  }
+  flip_to_upper_kernel<<<dim3(cdiv(C, 256), C), 256, 0, s>>>(Linv, Cp, C, H, ldh);
+  GPTQ_CHECK_LAUNCH("gptq_hinv_upper");
+  return GPTQ_OK;
+}

@@ -1,0 +1,60 @@
+// Shared helpers for the gfx950 GPTQ kernels (internal; the public C ABI is include/gptq_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/gptq_hip.h"
+
+namespace gptq {
+
+// Last error text (thread-local), exposed through gptq_last_error().
+void set_error(const char* fmt, ...);
+
+#define GPTQ_CHECK_ARG(cond, ...)                                   \
+  do {                                                              \
+    if (!(cond)) {                                                  \
+      ::gptq::set_error(__VA_ARGS__);                               \
+      return GPTQ_ERR_INVALID;                                      \
+    }                                                               \
+  } while (0)
+
+#define GPTQ_CHECK_LAUNCH(what)                                     \
+  do {                                                              \
+    hipError_t e_ = hipGetLastError();                              \
+    if (e_ != hipSuccess) {                                         \
+      ::gptq::set_error("%s: %s", what, hipGetErrorString(e_));     \
+      return GPTQ_ERR_HIP;                                          \
+    }                                                               \
+  } while (0)
+
+#define GPTQ_CHECK_HIP(expr)                                        \
+  do {                                                              \
+    hipError_t e_ = (expr);                                         \
+    if (e_ != hipSuccess) {                                         \
+      ::gptq::set_error("%s: %s", #expr, hipGetErrorString(e_));    \
+      return GPTQ_ERR_HIP;                                          \
+    }                                                               \
+  } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Bump allocator over a caller-provided workspace.
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* p) : base(static_cast<char*>(p)) {}
+  template <typename T>
+  T* take(size_t n) {
+    off = align_up(off, 256);
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+  size_t used() const { return align_up(off, 256); }
+};
+
+}  // namespace gptq

@@ -1,0 +1,497 @@
+// GPTQ solve: affine grids, the lazy-batch column loop and its trailing update
+// (replaces quant.py:6-10, 37-77 and gptq.py:126-305, default branch).
+//
+// Bit-exactness contract: find_params, quantize and the in-block loop perform the same IEEE fp32
+// operations in the same order as the reference's torch CPU ops (true division, round-half-even,
+// separate multiply and subtract -- this file is compiled with -ffp-contract=off), so identical
+// (W1, Hinv1, scale, zero) give identical bits.  Reductions (the trailing GEMM, the loss sum) are
+// tolerance-level: their summation order differs from MKL's.
+#include <algorithm>
+
+#include "gemm_f32.h"
+
+namespace gptq {
+
+// ---------------------------------------------------------------------------------------------
+// small utilities
+// ---------------------------------------------------------------------------------------------
+// gptq.py:143-145: dead = diag(H) == 0; H[dead, dead] = 1.  (W[:, dead] = 0 done by zero_dead_kernel.)
+__global__ void dead_fix_kernel(float* __restrict__ H, int ldh, int C, int32_t* __restrict__ dead,
+                                float* __restrict__ diag) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float* h = H + (long)c * ldh + c;
+  const bool d = (*h == 0.f);
+  if (d) *h = 1.f;
+  dead[c] = d;
+  diag[c] = d ? 1.f : *h;
+}
+
+__global__ void zero_dead_kernel(float* __restrict__ W, int ldw, int R, int C,
+                                 const int32_t* __restrict__ dead) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C || !dead[c]) return;
+  W[(long)blockIdx.y * ldw + c] = 0.f;
+}
+
+// perm = argsort(diag, descending), stable on ties (gptq.py:166; torch leaves tie order unspecified).
+__global__ __launch_bounds__(256) void argsort_desc_kernel(const float* __restrict__ diag, int C,
+                                                           int32_t* __restrict__ perm) {
+  __shared__ float tile[1024];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const float di = (i < C) ? diag[i] : 0.f;
+  int rank = 0;
+  for (int j0 = 0; j0 < C; j0 += 1024) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < 1024; t += 256) tile[t] = (j0 + t < C) ? diag[j0 + t] : 0.f;
+    __syncthreads();
+    const int n = min(1024, C - j0);
+    for (int t = 0; t < n; ++t) {
+      const float dj = tile[t];
+      rank += (dj > di) || (dj == di && j0 + t < i);
+    }
+  }
+  if (i < C) perm[rank] = i;
+}
+
+// dst[r][p] = src[r][perm[p]]  (gather = gptq.py:167)  or  dst[r][perm[p]] = src[r][p] (scatter = :301)
+template <typename T, bool SCATTER>
+__global__ void permute_cols_kernel(const T* __restrict__ src, int lds_, T* __restrict__ dst, int ldd,
+                                    int C, const int32_t* __restrict__ perm) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= C) return;
+  const long r = blockIdx.y;
+  if (SCATTER) dst[r * ldd + perm[p]] = src[r * lds_ + p];
+  else dst[r * ldd + p] = src[r * lds_ + perm[p]];
+}
+
+// col_group[p] = (perm ? perm[p] : p) / groupsize   (gptq.py:256-260)
+__global__ void col_group_kernel(int32_t* __restrict__ cg, int C, const int32_t* __restrict__ perm, int g) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < C) cg[p] = (perm ? perm[p] : p) / g;
+}
+
+__global__ void gather_tab_col_kernel(const float* __restrict__ stab, const float* __restrict__ ztab,
+                                      int tab_ld, const int32_t* __restrict__ cg, int last, int R,
+                                      float* __restrict__ s, float* __restrict__ z) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const int g = cg ? cg[last] : 0;
+  s[r] = stab[(long)r * tab_ld + g];
+  z[r] = ztab[(long)r * tab_ld + g];
+}
+
+__global__ __launch_bounds__(256) void sum_kernel(const float* __restrict__ x, int n, float* __restrict__ out) {
+  __shared__ double part[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += (double)x[i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = (float)part[0];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Quantizer.find_params (quant.py:37-77; perchannel, weight=True, mse=False): one wave per (row, group).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void find_params_kernel(const float* __restrict__ W, int ldw, int R,
+                                                          int c0, int c1, int gsize, float maxq, int sym,
+                                                          float* __restrict__ scale, float* __restrict__ zero,
+                                                          int tab_ld, int g0) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int j = blockIdx.y;
+  if (r >= R) return;
+  const int lo = c0 + j * gsize, hi = min(lo + gsize, c1);
+  const float* w = W + (long)r * ldw;
+  float mn = INFINITY, mx = -INFINITY;
+  for (int c = lo + lane; c < hi; c += 64) {
+    const float v = w[c];
+    mn = fminf(mn, v);
+    mx = fmaxf(mx, v);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, o));
+    mx = fmaxf(mx, __shfl_xor(mx, o));
+  }
+  if (lane != 0) return;
+  float xmin = fminf(mn, 0.f), xmax = fmaxf(mx, 0.f);          // quant.py:56-58
+  if (sym) {                                                   // quant.py:60-64
+    xmax = fmaxf(fabsf(xmin), xmax);
+    if (xmin < 0.f) xmin = -xmax;
+  }
+  if (xmin == 0.f && xmax == 0.f) { xmin = -1.f; xmax = 1.f; } // quant.py:65-67
+  const float s = (xmax - xmin) / maxq;                        // quant.py:73
+  const float z = sym ? (maxq + 1.f) / 2.f : rintf(-xmin / s); // quant.py:75,77
+  scale[(long)r * tab_ld + g0 + j] = s;
+  zero[(long)r * tab_ld + g0 + j] = z;
+}
+
+__device__ __forceinline__ float affine_code(float x, float s, float z, float maxq) {
+  return fminf(fmaxf(rintf(x / s) + z, 0.f), maxq);            // quant.py:9
+}
+
+__global__ void quantize_rows_kernel(float* __restrict__ X, int ldx, int R, int C,
+                                     const float* __restrict__ scale, const float* __restrict__ zero,
+                                     float maxq) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = blockIdx.y;
+  if (c >= C) return;
+  const float s = scale[r], z = zero[r];
+  float* x = X + (long)r * ldx + c;
+  *x = s * (affine_code(*x, s, z, maxq) - z);                  // quant.py:10
+}
+
+// ---------------------------------------------------------------------------------------------
+// In-block loop (gptq.py:201-271).  Rows are independent; a quad of lanes shares one row, lane c
+// holding block columns 4t + c in registers.  Per 4-column super-step the quad exchanges its four
+// current columns by DPP quad broadcast and every lane runs the same (bitwise identical) quantize
+// chain, so no cross-lane traffic sits on the sequential dependency chain.  The block is walked in
+// NPH phases of 32 columns; U rows of a phase are staged in LDS as Us[row][c][t] = U[i][4t + c].
+// ---------------------------------------------------------------------------------------------
+template <int Q>
+__device__ __forceinline__ float quad_bcast(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), Q * 0x55, 0xf, 0xf, true));
+}
+
+struct QuantBlockArgs {
+  float* W; int ldw; int R; int i1; int count;
+  const float* U; int ldu;
+  const float* scale_tab; const float* zero_tab; int tab_ld; const int32_t* col_group;
+  float maxq;
+  float* Err; uint8_t* codes; int ldc; const int32_t* col_map; float* loss;
+};
+
+template <int NPH, bool GROUPED>
+__global__ __launch_bounds__(256) void quant_block_kernel(QuantBlockArgs a) {
+  constexpr int B = 32 * NPH;
+  constexpr int NREG = 8 * NPH;
+  constexpr int LDCL = NREG + 4;               // padded class row (16-B aligned, conflict-free b128)
+  __shared__ __attribute__((aligned(16))) float Us[32 * 4 * LDCL];
+  __shared__ int grp[B];
+  __shared__ int cmap[B];
+
+  const int tid = threadIdx.x;
+  const int c = tid & 3;
+  const int row = blockIdx.x * 64 + (tid >> 2);
+  const bool active = row < a.R;
+  const long rbase = (long)(active ? row : 0);
+  float* wrow = a.W + rbase * a.ldw + a.i1;
+
+  for (int k = tid; k < B; k += 256) {
+    grp[k] = (a.col_group && k < a.count) ? a.col_group[a.i1 + k] : 0;
+    cmap[k] = (k < a.count) ? (a.col_map ? a.col_map[a.i1 + k] : a.i1 + k) : 0;
+  }
+
+  float w[NREG];
+#pragma unroll
+  for (int j = 0; j < NREG; ++j) {
+    const int col = 4 * j + c;
+    w[j] = (active && col < a.count) ? wrow[col] : 0.f;
+  }
+  float sc = 1.f, zr = 0.f;
+  if (!GROUPED && active) {
+    sc = a.scale_tab[rbase * a.tab_ld];
+    zr = a.zero_tab[rbase * a.tab_ld];
+  }
+  float loss = 0.f;
+
+#pragma unroll 1
+  for (int ph = 0; ph < NPH; ++ph) {
+    __syncthreads();
+    // stage the 32 U rows of this phase: Us[il][k & 3][k >> 2] = U[i][k], k >= i (upper), else 0
+    for (int idx = tid; idx < 32 * B; idx += 256) {
+      const int il = idx / B, k = idx % B;
+      const int i = 32 * ph + il;
+      float v = 0.f;
+      if (i < a.count && k >= i && k < a.count) v = a.U[(long)(a.i1 + i) * a.ldu + a.i1 + k];
+      Us[(il * 4 + (k & 3)) * LDCL + (k >> 2)] = v;
+    }
+    __syncthreads();
+
+    float e[8], cd[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { e[t] = 0.f; cd[t] = 0.f; }
+
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      float cur[4];
+      cur[0] = quad_bcast<0>(w[t]);
+      cur[1] = quad_bcast<1>(w[t]);
+      cur[2] = quad_bcast<2>(w[t]);
+      cur[3] = quad_bcast<3>(w[t]);
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const int il = 4 * t + cc;
+        const int i = 32 * ph + il;
+        if (i < a.count) {                                       // block-uniform
+          if (GROUPED) {
+            const int g = grp[i];
+            sc = active ? a.scale_tab[rbase * a.tab_ld + g] : 1.f;
+            zr = active ? a.zero_tab[rbase * a.tab_ld + g] : 0.f;
+          }
+          const float* urow = Us + il * 4 * LDCL;
+          const float x = cur[cc];
+          const float code = affine_code(x, sc, zr, a.maxq);     // gptq.py:262-264
+          const float q = sc * (code - zr);
+          const float d = urow[cc * LDCL + 8 * ph + t];          // Hinv1[i, i]
+          const float diff = x - q;
+          const float err = diff / d;                            // gptq.py:269
+          loss += (diff * diff) / (d * d);                       // gptq.py:267
+          if (c == cc) { w[t] = q; e[t] = err; cd[t] = code; }
+#pragma unroll
+          for (int c2 = cc + 1; c2 < 4; ++c2)                    // rest of this super-step (uniform)
+            cur[c2] -= err * urow[c2 * LDCL + 8 * ph + t];       // gptq.py:270
+          const float* ul = urow + c * LDCL + 8 * ph;
+#pragma unroll
+          for (int t2 = t + 1; t2 < 8; ++t2) w[t2] -= err * ul[t2];
+#pragma unroll
+          for (int g = 1; g < NPH; ++g) {
+            if (ph + g < NPH) {                                  // block-uniform
+#pragma unroll
+              for (int t2 = 0; t2 < 8; ++t2) w[8 * g + t2] -= err * ul[8 * g + t2];
+            }
+          }
+        }
+      }
+    }
+
+    // retire the window: Q1 -> W, Err1 -> Err, codes; then slide the registers down by one window
+    if (active) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int col = 32 * ph + 4 * t + c;
+        if (col < a.count) {
+          wrow[col] = w[t];
+          if (a.codes) a.codes[rbase * a.ldc + cmap[col]] = (uint8_t)cd[t];
+        }
+        a.Err[rbase * B + col] = (col < a.count) ? e[t] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j + 8 < NREG; ++j) w[j] = w[j + 8];
+  }
+  if (active && c == 0) a.loss[row] += 0.5f * loss;               // gptq.py:274
+}
+
+// W[:, i2:] -= Err1 @ U[i1:i2, i2:]   (gptq.py:276), exact-fp32 MFMA.
+__global__ __launch_bounds__(GEMM_THREADS) void trailing_kernel(float* __restrict__ W, int ldw, int R, int C,
+                                                                int i1, int i2, int B,
+                                                                const float* __restrict__ Err,
+                                                                const float* __restrict__ U, int ldu,
+                                                                bool bvec) {
+  __shared__ __attribute__((aligned(16))) float smem[GEMM_LDS_FLOATS];
+  const int tn = blockIdx.x, tm = blockIdx.y;
+  const long r0 = (long)tm * GBM, c0 = (long)i2 + (long)tn * GBN;
+  Operand<float> a{Err + r0 * B, B, 1, (int)min((long)GBM, R - r0), true};
+  Operand<float> b{U + (long)i1 * ldu + c0, 1, ldu, (int)min((long)GBN, C - c0), bvec};
+  float* Wt = W + r0 * ldw + c0;
+  gemm_tile<float, float, true, false>(a, b, 0, B, smem,
+                                       [=](int r, int c, float v) { Wt[(long)r * ldw + c] -= v; });
+}
+
+}  // namespace gptq
+
+using namespace gptq;
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" int gptq_find_params(const float* W, int ldw, int R, int c0, int c1, int gsize, int bits,
+                                int sym, float* scale, float* zero, int tab_ld, int g0,
+                                gptq_stream_t stream) {
+  GPTQ_CHECK_ARG(W && scale && zero, "gptq_find_params: null pointer");
+  GPTQ_CHECK_ARG(R > 0 && c0 >= 0 && c1 > c0 && gsize > 0 && ldw >= c1, "gptq_find_params: bad sizes");
+  GPTQ_CHECK_ARG(bits >= 1 && bits <= 8, "gptq_find_params: bits must be in 1..8 (trits are out of scope)");
+  const int ng = cdiv(c1 - c0, gsize);
+  GPTQ_CHECK_ARG(tab_ld >= g0 + ng, "gptq_find_params: table too narrow");
+  const float maxq = (float)((1 << bits) - 1);
+  find_params_kernel<<<dim3(cdiv(R, 4), ng), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      W, ldw, R, c0, c1, gsize, maxq, sym, scale, zero, tab_ld, g0);
+  GPTQ_CHECK_LAUNCH("find_params_kernel");
+  return GPTQ_OK;
+}
+
+extern "C" int gptq_quantize_rows(float* X, int ldx, int R, int C, const float* scale, const float* zero,
+                                  int bits, gptq_stream_t stream) {
+  GPTQ_CHECK_ARG(X && scale && zero && R > 0 && C > 0 && ldx >= C, "gptq_quantize_rows: bad arguments");
+  GPTQ_CHECK_ARG(bits >= 1 && bits <= 8, "gptq_quantize_rows: bits must be in 1..8");
+  GPTQ_CHECK_ARG(R <= 65535, "gptq_quantize_rows: R too large");
+  quantize_rows_kernel<<<dim3(cdiv(C, 256), R), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      X, ldx, R, C, scale, zero, (float)((1 << bits) - 1));
+  GPTQ_CHECK_LAUNCH("quantize_rows_kernel");
+  return GPTQ_OK;
+}
+
+static int launch_quant_block(const QuantBlockArgs& a, int blocksize, bool grouped, hipStream_t s) {
+  const int grid = cdiv(a.R, 64);
+#define QB_CASE(NPH)                                                                  \
+  case 32 * NPH:                                                                      \
+    if (grouped) quant_block_kernel<NPH, true><<<grid, 256, 0, s>>>(a);               \
+    else quant_block_kernel<NPH, false><<<grid, 256, 0, s>>>(a);                      \
+    break;
+  switch (blocksize) {
+    QB_CASE(1) QB_CASE(2) QB_CASE(4) QB_CASE(8)
+    default:
+      set_error("blocksize %d unsupported (32, 64, 128 or 256)", blocksize);
+      return GPTQ_ERR_UNSUPPORTED;
+  }
+#undef QB_CASE
+  GPTQ_CHECK_LAUNCH("quant_block_kernel");
+  return GPTQ_OK;
+}
+
+extern "C" int gptq_quant_block(float* W, int ldw, int R, int C, int i1, int count, int blocksize,
+                                const float* U, int ldu, const float* scale_tab, const float* zero_tab,
+                                int tab_ld, const int32_t* col_group, int bits, float* Err,
+                                uint8_t* codes, int ldc, const int32_t* col_map, float* loss,
+                                gptq_stream_t stream) {
+  GPTQ_CHECK_ARG(W && U && scale_tab && zero_tab && Err && loss, "gptq_quant_block: null pointer");
+  GPTQ_CHECK_ARG(R > 0 && C > 0 && i1 >= 0 && count > 0 && count <= blocksize && i1 + count <= C,
+                 "gptq_quant_block: bad block range");
+  GPTQ_CHECK_ARG(ldw >= C && ldu >= C && tab_ld >= 1, "gptq_quant_block: bad leading dimension");
+  GPTQ_CHECK_ARG(bits >= 1 && bits <= 8, "gptq_quant_block: bits must be in 1..8");
+  QuantBlockArgs a{W, ldw, R, i1, count, U, ldu, scale_tab, zero_tab, tab_ld, col_group,
+                   (float)((1 << bits) - 1), Err, codes, ldc, col_map, loss};
+  return launch_quant_block(a, blocksize, col_group != nullptr, static_cast<hipStream_t>(stream));
+}
+
+namespace {
+struct SolveWs {
+  float* Wp; float* Err; float* loss; float* diag; float* stab; float* ztab;
+  int32_t* dead; int32_t* perm; int32_t* cgroup; void* hinv; size_t hinv_bytes; size_t total;
+};
+SolveWs carve_solve(void* base, int R, int C, int blocksize, int groupsize, int actorder) {
+  Carver cv(base);
+  SolveWs w{};
+  const int G = groupsize > 0 ? cdiv(C, groupsize) : 1;
+  w.Wp = actorder ? cv.take<float>((size_t)R * C) : nullptr;
+  w.Err = cv.take<float>((size_t)R * blocksize);
+  w.loss = cv.take<float>(R);
+  w.diag = cv.take<float>(C);
+  w.stab = cv.take<float>((size_t)R * G);
+  w.ztab = cv.take<float>((size_t)R * G);
+  w.dead = cv.take<int32_t>(C);
+  w.perm = cv.take<int32_t>(C);
+  w.cgroup = cv.take<int32_t>(C);
+  w.hinv_bytes = gptq_hinv_workspace_bytes(C);
+  w.hinv = cv.take<char>(w.hinv_bytes);
+  w.total = cv.used();
+  return w;
+}
+}  // namespace
+
+extern "C" size_t gptq_fasterquant_workspace_bytes(int R, int C, int blocksize, int groupsize,
+                                                   int actorder, int static_groups) {
+  (void)static_groups;
+  if (R <= 0 || C <= 0 || blocksize <= 0) return 0;
+  return carve_solve(nullptr, R, C, blocksize, groupsize, actorder).total;
+}
+
+extern "C" int gptq_fasterquant(float* W, int ldw, float* H, int ldh, int R, int C, int bits, int sym,
+                                int blocksize, float percdamp, int groupsize, int actorder,
+                                int static_groups, float* scale_io, float* zero_io, int preset,
+                                float* group_scale, float* group_zero, int32_t* perm_out,
+                                uint8_t* codes, float* error_out, int32_t* info, void* workspace,
+                                size_t workspace_bytes, gptq_stream_t stream) {
+  GPTQ_CHECK_ARG(W && H && scale_io && zero_io && error_out && workspace, "gptq_fasterquant: null pointer");
+  GPTQ_CHECK_ARG(R > 0 && C > 0 && ldw >= C && ldh >= C, "gptq_fasterquant: bad sizes");
+  GPTQ_CHECK_ARG(R <= 65535, "gptq_fasterquant: R too large");
+  GPTQ_CHECK_ARG(bits >= 1 && bits <= 8, "gptq_fasterquant: bits must be in 1..8 (trits are out of scope)");
+  GPTQ_CHECK_ARG(groupsize == -1 || groupsize > 0, "gptq_fasterquant: groupsize must be -1 or positive");
+  if (blocksize != 32 && blocksize != 64 && blocksize != 128 && blocksize != 256) {
+    set_error("gptq_fasterquant: blocksize %d unsupported (32, 64, 128 or 256)", blocksize);
+    return GPTQ_ERR_UNSUPPORTED;
+  }
+  GPTQ_CHECK_ARG(reinterpret_cast<uintptr_t>(workspace) % 256 == 0, "gptq_fasterquant: workspace must be 256-byte aligned");
+  GPTQ_CHECK_ARG(workspace_bytes >= gptq_fasterquant_workspace_bytes(R, C, blocksize, groupsize, actorder, static_groups),
+                 "gptq_fasterquant: workspace too small");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const SolveWs ws = carve_solve(workspace, R, C, blocksize, groupsize, actorder);
+  const bool grouped = groupsize > 0;
+  const bool use_static = static_groups && grouped;   // range(0, C, -1) is empty (gptq.py:159)
+  const int G = grouped ? cdiv(C, groupsize) : 1;
+  const float maxq = (float)((1 << bits) - 1);
+  const int TB = 256;
+
+  // dead columns (gptq.py:143-145)
+  dead_fix_kernel<<<cdiv(C, TB), TB, 0, s>>>(H, ldh, C, ws.dead, ws.diag);
+  zero_dead_kernel<<<dim3(cdiv(C, TB), R), TB, 0, s>>>(W, ldw, R, C, ws.dead);
+
+  // static groups: grids of the ORIGINAL, uncompensated columns (gptq.py:157-163)
+  if (use_static)
+    find_params_kernel<<<dim3(cdiv(R, 4), G), 256, 0, s>>>(W, ldw, R, 0, C, groupsize, maxq, sym,
+                                                           ws.stab, ws.ztab, G, 0);
+  // act-order (gptq.py:165-169)
+  float* Wk = W;
+  int ldk = ldw;
+  const int32_t* perm = nullptr;
+  if (actorder) {
+    argsort_desc_kernel<<<cdiv(C, 256), 256, 0, s>>>(ws.diag, C, ws.perm);
+    permute_cols_kernel<float, false><<<dim3(cdiv(C, TB), R), TB, 0, s>>>(W, ldw, ws.Wp, C, C, ws.perm);
+    Wk = ws.Wp;
+    ldk = C;
+    perm = ws.perm;
+    if (perm_out) GPTQ_CHECK_HIP(hipMemcpyAsync(perm_out, ws.perm, sizeof(int32_t) * C, hipMemcpyDeviceToDevice, s));
+  }
+  // damped inverse factor (gptq.py:174-180): H <- U
+  {
+    const int rc = gptq_hinv_upper(H, ldh, C, percdamp, perm, info, ws.hinv, ws.hinv_bytes, stream);
+    if (rc != GPTQ_OK) return rc;
+  }
+  // full-row grid unless the quantizer is ready (gptq.py:181-185)
+  if (!grouped) {
+    if (preset) {
+      GPTQ_CHECK_HIP(hipMemcpyAsync(ws.stab, scale_io, sizeof(float) * R, hipMemcpyDeviceToDevice, s));
+      GPTQ_CHECK_HIP(hipMemcpyAsync(ws.ztab, zero_io, sizeof(float) * R, hipMemcpyDeviceToDevice, s));
+    } else {
+      find_params_kernel<<<dim3(cdiv(R, 4), 1), 256, 0, s>>>(Wk, ldk, R, 0, C, C, maxq, sym, ws.stab, ws.ztab, 1, 0);
+    }
+  } else {
+    col_group_kernel<<<cdiv(C, TB), TB, 0, s>>>(ws.cgroup, C, use_static ? perm : nullptr, groupsize);
+  }
+  GPTQ_CHECK_HIP(hipMemsetAsync(ws.loss, 0, sizeof(float) * R, s));
+
+  const bool bvec_base = (ldh % 4 == 0) && (reinterpret_cast<uintptr_t>(H) % 16 == 0);
+  for (int i1 = 0; i1 < C; i1 += blocksize) {                    // gptq.py:191
+    const int i2 = std::min(i1 + blocksize, C);
+    const int count = i2 - i1;
+    if (grouped && !use_static) {
+      // dynamic groups starting inside this block read the CURRENT global W (gptq.py:253-255)
+      const int first = cdiv(i1, groupsize) * groupsize;
+      if (first < i2) {
+        const int ngb = cdiv(i2 - first, groupsize);
+        const int c1 = std::min(C, first + ngb * groupsize);
+        find_params_kernel<<<dim3(cdiv(R, 4), ngb), 256, 0, s>>>(Wk, ldk, R, first, c1, groupsize, maxq, sym,
+                                                                 ws.stab, ws.ztab, G, first / groupsize);
+      }
+    }
+    QuantBlockArgs a{Wk, ldk, R, i1, count, H, ldh, ws.stab, ws.ztab, G,
+                     grouped ? ws.cgroup : nullptr, maxq, ws.Err, codes, C, perm, ws.loss};
+    const int rc = launch_quant_block(a, blocksize, grouped, s);
+    if (rc != GPTQ_OK) return rc;
+    if (i2 < C) {
+      const bool bvec = bvec_base && (i2 % 4 == 0);
+      trailing_kernel<<<dim3(cdiv(C - i2, GBN), cdiv(R, GBM)), GEMM_THREADS, 0, s>>>(
+          Wk, ldk, R, C, i1, i2, blocksize, ws.Err, H, ldh, bvec);
+    }
+  }
+  if (actorder)                                                  // gptq.py:300-301
+    permute_cols_kernel<float, true><<<dim3(cdiv(C, TB), R), TB, 0, s>>>(ws.Wp, C, W, ldw, C, ws.perm);
+
+  // grid left in the quantizer + optional tables + sum(Losses) (gptq.py:294)
+  gather_tab_col_kernel<<<cdiv(R, TB), TB, 0, s>>>(ws.stab, ws.ztab, G, grouped ? ws.cgroup : nullptr,
+                                                   C - 1, R, scale_io, zero_io);
+  if (grouped && group_scale && group_zero) {
+    GPTQ_CHECK_HIP(hipMemcpyAsync(group_scale, ws.stab, sizeof(float) * (size_t)R * G, hipMemcpyDeviceToDevice, s));
+    GPTQ_CHECK_HIP(hipMemcpyAsync(group_zero, ws.ztab, sizeof(float) * (size_t)R * G, hipMemcpyDeviceToDevice, s));
+  }
+  sum_kernel<<<1, 256, 0, s>>>(ws.loss, R, error_out);
+  GPTQ_CHECK_LAUNCH("gptq_fasterquant");
+  return GPTQ_OK;
+}

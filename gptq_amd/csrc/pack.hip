@@ -1,0 +1,139 @@
+// int3 / int4 bit packing on the GPU  (replaces Quant3Linear.pack, quant.py:152-187 -- a host
+// numpy loop the reference itself marks "TODO: perform packing on GPU", opt.py:361 -- and the
+// int4 layout of zeroShot/models/quant.py:176-185).  HBM-bound: reads the [out, in] weights once
+// (coalesced along `in`), transposes 64 x 128 tiles of integer codes through LDS, and writes the
+// [in/32*bits, out] words coalesced along `out`.  Bit-exact, including the reference's uint32
+// wrap-around for out-of-range codes.
+#include "common.h"
+
+namespace gptq {
+
+constexpr int PT_O = 64;    // output features per tile
+constexpr int PT_I = 128;   // input features per tile (4 groups of 32)
+
+template <typename T> __device__ __forceinline__ float pk_to_f32(T v);
+template <> __device__ __forceinline__ float pk_to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float pk_to_f32<__half>(__half v) { return __half2float(v); }
+template <> __device__ __forceinline__ float pk_to_f32<__hip_bfloat16>(__hip_bfloat16 v) { return __bfloat162float(v); }
+
+// 32 codes (uint32 each, reference semantics) -> 3 words: the 96-bit little-endian stream of
+// quant.py:166-183, written with the same shifts / masks so that wrap-around matches bit for bit.
+__device__ __forceinline__ void pack3_words(const uint32_t* v, int stride, uint32_t out[3]) {
+  uint32_t w0 = 0, w1 = 0, w2 = 0;
+#pragma unroll
+  for (int j = 0; j < 10; ++j) w0 |= v[j * stride] << (3 * j);
+  w0 |= v[10 * stride] << 30;
+  w1 |= (v[10 * stride] >> 2) & 1u;
+#pragma unroll
+  for (int j = 0; j < 10; ++j) w1 |= v[(11 + j) * stride] << (3 * j + 1);
+  w1 |= v[21 * stride] << 31;
+  w2 |= (v[21 * stride] >> 1) & 3u;
+#pragma unroll
+  for (int j = 0; j < 10; ++j) w2 |= v[(22 + j) * stride] << (3 * j + 2);
+  out[0] = w0; out[1] = w1; out[2] = w2;
+}
+
+// SRC = 0: weights (T) + per-row scale / zero*scale -> codes;  SRC = 1: ready uint8 codes.
+template <typename T, int BITS, int SRC>
+__global__ __launch_bounds__(256) void pack_kernel(const T* __restrict__ src, int lds_, int n_out, int n_in,
+                                                   const float* __restrict__ scales,
+                                                   const float* __restrict__ zeros,
+                                                   int32_t* __restrict__ qweight) {
+  __shared__ uint32_t cs[PT_O][PT_I + 1];
+  const int tid = threadIdx.x;
+  const int o0 = blockIdx.y * PT_O, i0 = blockIdx.x * PT_I;
+
+  // read phase: 32 lanes x 4 consecutive inputs = one 128-wide row slice; 8 rows per pass
+  const int il = (tid & 31) * 4;
+#pragma unroll
+  for (int pass = 0; pass < PT_O / 8; ++pass) {
+    const int ol = pass * 8 + (tid >> 5);
+    const int o = o0 + ol;
+    float s = 1.f, zs = 0.f;
+    if (SRC == 0 && o < n_out) { s = scales[o]; zs = zeros[o]; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = i0 + il + e;
+      uint32_t code = 0;
+      if (o < n_out && i < n_in) {
+        if (SRC == 0) {
+          const float w = pk_to_f32<T>(src[(long)o * lds_ + i]);
+          code = (uint32_t)(int32_t)rintf((w + zs) / s);     // quant.py:158
+        } else {
+          code = (uint32_t)reinterpret_cast<const uint8_t*>(src)[(long)o * lds_ + i];
+        }
+      }
+      cs[ol][il + e] = code;
+    }
+  }
+  __syncthreads();
+
+  // pack phase: thread = (output ol, 32-group g); consecutive lanes -> consecutive outputs
+  const int ol = tid & 63, g = tid >> 6;
+  const int o = o0 + ol;
+  const int gi = i0 / 32 + g;                    // global 32-group index
+  if (o >= n_out || (gi + 1) * 32 > n_in) return;
+  const uint32_t* v = &cs[ol][32 * g];
+  if (BITS == 3) {
+    uint32_t w[3];
+    pack3_words(v, 1, w);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) qweight[((long)gi * 3 + k) * n_out + o] = (int32_t)w[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                // zeroShot/models/quant.py:185
+      uint32_t w = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w |= v[8 * k + j] << (4 * j);
+      qweight[((long)gi * 4 + k) * n_out + o] = (int32_t)w;
+    }
+  }
+}
+
+template <typename T, int SRC>
+static int launch_pack(const T* src, int ld, int n_out, int n_in, const float* scales, const float* zeros,
+                       int bits, int32_t* qweight, hipStream_t s) {
+  const dim3 grid(cdiv(n_in, PT_I), cdiv(n_out, PT_O));
+  if (bits == 3) pack_kernel<T, 3, SRC><<<grid, 256, 0, s>>>(src, ld, n_out, n_in, scales, zeros, qweight);
+  else pack_kernel<T, 4, SRC><<<grid, 256, 0, s>>>(src, ld, n_out, n_in, scales, zeros, qweight);
+  GPTQ_CHECK_LAUNCH("pack_kernel");
+  return GPTQ_OK;
+}
+
+}  // namespace gptq
+
+using namespace gptq;
+
+static int check_pack_shape(const char* who, int out_features, int in_features, int bits) {
+  GPTQ_CHECK_ARG(bits == 3 || bits == 4, "%s: bits must be 3 or 4", who);
+  GPTQ_CHECK_ARG(out_features > 0 && in_features > 0, "%s: bad sizes", who);
+  GPTQ_CHECK_ARG(in_features % 32 == 0, "%s: in_features must be a multiple of 32", who);
+  return GPTQ_OK;
+}
+
+extern "C" int gptq_pack_weights(const void* weight, int w_dtype, int ldw, int out_features, int in_features,
+                                 const float* scales, const float* zeros, int bits, int32_t* qweight,
+                                 gptq_stream_t stream) {
+  GPTQ_CHECK_ARG(weight && scales && zeros && qweight, "gptq_pack_weights: null pointer");
+  if (int rc = check_pack_shape("gptq_pack_weights", out_features, in_features, bits)) return rc;
+  GPTQ_CHECK_ARG(ldw >= in_features, "gptq_pack_weights: leading dimension too small");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (w_dtype) {
+    case GPTQ_F32:
+      return launch_pack<float, 0>(static_cast<const float*>(weight), ldw, out_features, in_features, scales, zeros, bits, qweight, s);
+    case GPTQ_F16:
+      return launch_pack<__half, 0>(static_cast<const __half*>(weight), ldw, out_features, in_features, scales, zeros, bits, qweight, s);
+    case GPTQ_BF16:
+      return launch_pack<__hip_bfloat16, 0>(static_cast<const __hip_bfloat16*>(weight), ldw, out_features, in_features, scales, zeros, bits, qweight, s);
+  }
+  GPTQ_CHECK_ARG(false, "gptq_pack_weights: unknown dtype %d", w_dtype);
+}
+
+extern "C" int gptq_pack_codes(const uint8_t* codes, int ldc, int out_features, int in_features, int bits,
+                               int32_t* qweight, gptq_stream_t stream) {
+  GPTQ_CHECK_ARG(codes && qweight, "gptq_pack_codes: null pointer");
+  if (int rc = check_pack_shape("gptq_pack_codes", out_features, in_features, bits)) return rc;
+  GPTQ_CHECK_ARG(ldc >= in_features, "gptq_pack_codes: leading dimension too small");
+  return launch_pack<float, 1>(reinterpret_cast<const float*>(codes), ldc, out_features, in_features,
+                               nullptr, nullptr, bits, qweight, static_cast<hipStream_t>(stream));
+}

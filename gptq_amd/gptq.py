@@ -1,0 +1,178 @@
+"""GPTQ solver object with the reference's protocol (gptq.py:23-318), backed by libgptq_hip.so.
+
+Callers construct `GPTQ(linear)`, assign `.quantizer`, feed `add_batch(inp, out)` from a
+forward hook, call `fasterquant(...)`, read `.quantizer` back and `free()` (opt.py:172-214).
+Host orchestration only: every FLOP of the path (Hessian SYRK, damped inverse factor,
+column loop, trailing updates) is a gfx950 kernel behind the C ABI in include/gptq_hip.h.
+"""
+from __future__ import annotations
+
+import math
+import time
+
+import torch
+import torch.nn as nn
+
+try:  # Conv1D support mirrors gptq.py:31-32; transformers is optional here
+    import transformers
+    _Conv1D = transformers.Conv1D
+except Exception:  # pragma: no cover
+    _Conv1D = ()
+
+from . import _lib
+from .quant import *  # noqa: F401,F403  (the reference's gptq.py re-exports quant.*, drivers rely on it)
+
+DEBUG = False
+VERBOSE = True   # the reference prints `time` / `error` per layer (gptq.py:293-294)
+
+
+class GPTQ:
+
+    def __init__(self, layer):
+        self.layer = layer
+        self.dev = self.layer.weight.device
+        _lib.require_gpu(layer.weight, "layer.weight")
+        shape = layer.weight.shape
+        if isinstance(layer, nn.Conv2d):
+            self.rows, self.columns = shape[0], int(math.prod(shape[1:]))
+        elif _Conv1D and isinstance(layer, _Conv1D):
+            self.rows, self.columns = shape[1], shape[0]
+        else:
+            self.rows, self.columns = shape[0], shape[1]
+        self._H = torch.zeros((self.columns, self.columns), device=self.dev, dtype=torch.float32)
+        self._lower_stale = False   # add_batch maintains the upper triangle only
+        self.nsamples = 0
+
+    # -- H stays reachable as a full symmetric tensor; mirrored lazily -------------
+    @property
+    def H(self):
+        if self._H is not None and self._lower_stale:
+            with torch.cuda.device(self.dev):
+                _lib.call("gptq_symmetrize", _lib.ptr(self._H), self._H.stride(0), self.columns, _lib.stream(self.dev))
+            self._lower_stale = False
+        return self._H
+
+    @H.setter
+    def H(self, value):
+        self._H = value
+        self._lower_stale = False
+
+    @H.deleter
+    def H(self):
+        self._H = None
+
+    def add_batch(self, inp, out):
+        """Running-mean Hessian update (gptq.py:38-65): H <- H*n/(n+b) + 2/(n+b) X^T X."""
+        if DEBUG:
+            self.inp1 = inp
+            self.out1 = out
+        if len(inp.shape) == 2:
+            inp = inp.unsqueeze(0)
+        batch = inp.shape[0]
+        if isinstance(self.layer, nn.Conv2d):
+            unfold = nn.Unfold(self.layer.kernel_size, dilation=self.layer.dilation,
+                               padding=self.layer.padding, stride=self.layer.stride)
+            x = unfold(inp).permute(0, 2, 1).reshape(-1, self.columns)      # tokens x (C*kh*kw)
+        else:
+            x = inp.reshape(-1, inp.shape[-1])                              # tokens x C
+        _lib.require_gpu(x, "inp")
+        if x.dtype not in (torch.float16, torch.bfloat16, torch.float32):
+            x = x.float()
+        if x.stride(-1) != 1:
+            x = x.contiguous()
+        if x.shape[1] != self.columns:
+            raise ValueError(f"add_batch: input has {x.shape[1]} features, layer expects {self.columns}")
+        with torch.cuda.device(self.dev):
+            _lib.call("gptq_hessian_accum", _lib.ptr(self._H), self._H.stride(0), _lib.ptr(x), _lib.dtype_code(x),
+                      x.stride(0), self.columns, x.shape[0], int(self.nsamples), int(batch), _lib.stream(self.dev))
+        self._lower_stale = True
+        self.nsamples += batch
+        # fork addition (gptq.py:63): token mean of the scaled batch; not used by the default branch
+        self.input = x.mean(0, dtype=torch.float32) * math.sqrt(2 / self.nsamples)
+
+    def fasterquant(self, blocksize=128, percdamp=.01, groupsize=-1, actorder=False, static_groups=False,
+                    model_name="opt", layer_name="layer", lut_quant=False, non_linear_quant=False,
+                    columnwise=False):
+        """Damped inverse factor + blocked quantize-and-compensate loop (gptq.py:126-305).
+
+        The fork-only branches (`lut_quant`, `non_linear_quant`, `columnwise`) are outside the
+        MI355X hot-path scope and raise.
+        """
+        if lut_quant or non_linear_quant or columnwise:
+            raise NotImplementedError("lut_quant / non_linear_quant / columnwise are fork experiments outside "
+                                      "the MI355X hot-path scope")
+        q = self.quantizer
+        bits = int(getattr(q, "wbits", 0)) or (int(q.maxq) + 1).bit_length() - 1
+        if int(q.maxq) < 0:
+            raise NotImplementedError("trits are outside the MI355X hot-path scope")
+        W = self.layer.weight.data.clone()
+        if isinstance(self.layer, nn.Conv2d):
+            W = W.flatten(1)
+        if _Conv1D and isinstance(self.layer, _Conv1D):
+            W = W.t()
+        W = W.float().contiguous()
+        R, C = W.shape
+        dev = self.dev
+
+        tick = time.time()
+        H = self._H                      # upper triangle is all the solver reads
+        self._H = None                   # consumed, like `del self.H` (gptq.py:141-142)
+        if H is None:
+            raise RuntimeError("fasterquant: H was already consumed or freed")
+        G = -(-C // groupsize) if groupsize > 0 else 0
+        scale = torch.zeros(R, device=dev, dtype=torch.float32)
+        zero = torch.zeros(R, device=dev, dtype=torch.float32)
+        preset = 0
+        if q.scale.numel() == R and bool(q.ready()):          # gptq.py:181
+            scale.copy_(q.scale.reshape(-1))
+            zero.copy_(q.zero.reshape(-1))
+            preset = 1
+        gscale = torch.empty((R, G), device=dev, dtype=torch.float32) if G else None
+        gzero = torch.empty((R, G), device=dev, dtype=torch.float32) if G else None
+        perm = torch.empty(C, device=dev, dtype=torch.int32) if actorder else None
+        codes = torch.empty((R, C), device=dev, dtype=torch.uint8)
+        stat = torch.zeros(2, device=dev, dtype=torch.float32)          # [error, info (int32 bits)]
+        info = stat[1:].view(torch.int32)
+        lib = _lib.load()
+        nbytes = lib.gptq_fasterquant_workspace_bytes(R, C, int(blocksize), int(groupsize), int(bool(actorder)),
+                                                      int(bool(static_groups)))
+        ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        with torch.cuda.device(dev):
+            _lib.call("gptq_fasterquant", _lib.ptr(W), W.stride(0), _lib.ptr(H), H.stride(0), R, C, bits,
+                      int(bool(q.sym)), int(blocksize), float(percdamp), int(groupsize), int(bool(actorder)),
+                      int(bool(static_groups)), _lib.ptr(scale), _lib.ptr(zero), preset, _lib.ptr(gscale),
+                      _lib.ptr(gzero), _lib.ptr(perm), _lib.ptr(codes), _lib.ptr(stat), _lib.ptr(info),
+                      _lib.ptr(ws), nbytes, _lib.stream(dev))
+        host = stat.cpu()                # one sync, like torch.cuda.synchronize() at gptq.py:292
+        bad = int(host[1:].view(torch.int32).item())
+        if bad:
+            raise torch.linalg.LinAlgError(
+                f"fasterquant: the damped Hessian is not positive-definite (pivot {bad}); cf. torch.linalg.cholesky")
+        self.error = float(host[0].item())
+        if VERBOSE:
+            print('time %.2f' % (time.time() - tick))
+            print('error', self.error)
+
+        # state the callers read back (gptq.py:213, 305) + what packing grouped models needs
+        q.maxq = q.maxq.to(dev)
+        q.scale = scale.reshape(-1, 1)
+        q.zero = zero.reshape(-1, 1)
+        self.Hinv = H
+        self.codes = codes
+        self.group_scale, self.group_zero = gscale, gzero
+        self.perm = perm
+        Q = W
+        if _Conv1D and isinstance(self.layer, _Conv1D):
+            Q = Q.t()
+        self.layer.weight.data = Q.reshape(self.layer.weight.shape).to(self.layer.weight.data.dtype)
+
+    def free(self):
+        if DEBUG:
+            self.inp1 = None
+            self.out1 = None
+        self._H = None
+        self.Hinv = None
+        self.codes = None
+        self.Losses = None
+        self.Trace = None
+        torch.cuda.empty_cache()

@@ -1,0 +1,153 @@
+/*
+ * gptq_hip.h -- C ABI of libgptq_hip.so, the MI355X (gfx950) GPTQ hot path.
+ *
+ * Drop-in boundary for the reference's per-Linear GPTQ path.  Every entry point
+ * names the reference interface it replaces (paths relative to the reference
+ * checkout).  All pointers are DEVICE pointers borrowed for the duration of the
+ * call; nothing is allocated on behalf of the caller; outputs are written in
+ * place.  `stream` is a hipStream_t (NULL = default stream).  Calls only
+ * enqueue work on `stream` and never synchronise the device.
+ *
+ * Return value: 0 = ok, GPTQ_ERR_INVALID = bad argument/shape,
+ * GPTQ_ERR_HIP = HIP runtime error, GPTQ_ERR_UNSUPPORTED = option outside the
+ * hot-path scope.  gptq_last_error() returns a thread-local message.
+ */
+#ifndef GPTQ_HIP_H
+#define GPTQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPTQ_OK 0
+#define GPTQ_ERR_INVALID 1
+#define GPTQ_ERR_HIP 2
+#define GPTQ_ERR_UNSUPPORTED 3
+
+/* element types of activations / weights handed to the library */
+#define GPTQ_F32 0
+#define GPTQ_F16 1
+#define GPTQ_BF16 2
+
+typedef void* gptq_stream_t;
+
+int gptq_hip_abi_version(void);
+const char* gptq_last_error(void);
+
+/* ---------------------------------------------------------------------------
+ * Hessian running mean -- replaces GPTQ.add_batch (gptq.py:38-65):
+ *   H <- H * n/(n+b) + (2/(n+b)) * X^T X,   n = nsamples_before, b = batch.
+ * X: [tokens, C] row-major, leading dimension ldx elements, dtype x_dtype
+ * (fp16/bf16 activations are widened to fp32 on load, gptq.py:62); H: [C, C]
+ * fp32, leading dimension ldh.  Only the upper triangle (row <= col) of H is
+ * maintained; call gptq_symmetrize before reading H as a full matrix.
+ * ------------------------------------------------------------------------- */
+int gptq_hessian_accum(float* H, int ldh, const void* X, int x_dtype, int ldx, int C, int tokens,
+                       int nsamples_before, int batch, gptq_stream_t stream);
+
+/* Mirror the upper triangle of A [n, n] into the lower triangle. */
+int gptq_symmetrize(float* A, int lda, int n, gptq_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Affine grid -- replaces Quantizer.find_params (quant.py:37-77, perchannel,
+ * weight=True, mse=False) and quantize() (quant.py:6-10).
+ * find_params: for every row r and every group j (columns c0 + j*gsize ...,
+ * clipped to c1), writes scale[r*tab_ld + g0 + j], zero[...].
+ * ------------------------------------------------------------------------- */
+int gptq_find_params(const float* W, int ldw, int R, int c0, int c1, int gsize, int bits, int sym,
+                     float* scale, float* zero, int tab_ld, int g0, gptq_stream_t stream);
+
+/* Round-to-nearest onto a per-row grid (the `--nearest` baseline, opt.py:289-300):
+ * X[r, c] <- scale[r] * (clamp(rint(X/scale[r]) + zero[r], 0, 2^bits-1) - zero[r]). */
+int gptq_quantize_rows(float* X, int ldx, int R, int C, const float* scale, const float* zero,
+                       int bits, gptq_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Damped inverse factor -- replaces gptq.py:174-180
+ *   (H[diag] += percdamp*mean(diag H); cholesky; cholesky_inverse; cholesky(upper)).
+ * In: H [C, C] fp32, upper triangle valid (dead-column fix already applied).
+ * perm (nullable, int32[C]): act-order permutation, H <- H[perm][:, perm] first
+ * (gptq.py:168).  Out: H is overwritten by U (upper triangular, U^T U =
+ * (H + damp I)^-1, zero below the diagonal).  info (device int32[1], nullable)
+ * is set non-zero if a non-positive pivot was met (torch raises LinAlgError).
+ * ------------------------------------------------------------------------- */
+size_t gptq_hinv_workspace_bytes(int C);
+int gptq_hinv_upper(float* H, int ldh, int C, float percdamp, const int32_t* perm, int32_t* info,
+                    void* workspace, size_t workspace_bytes, gptq_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * One lazy-batch block of the column loop -- replaces gptq.py:195-274 for a
+ * single block [i1, i1+count) with the plain affine quantizer (gptq.py:251-264).
+ * W [R, C] fp32 working weights: columns [i1, i1+count) are replaced by the
+ * dequantized Q1; Err [R, blocksize] receives Err1 (zero past count).
+ * U: upper factor [C, C].  The grid of column i1+i of row r is
+ *   scale_tab[r*tab_ld + col_group[i1+i]]  (col_group NULL => column 0).
+ * codes (nullable, uint8 [R, ldc]) receives the integer code of column i1+i at
+ * codes[r*ldc + (col_map ? col_map[i1+i] : i1+i)].
+ * loss [R] fp32 accumulates sum_i (w-q)^2 / d^2 / 2 per row (gptq.py:267,274).
+ * Bit-exact with the reference loop when fed identical (W1, Hinv1, scale, zero).
+ * ------------------------------------------------------------------------- */
+int gptq_quant_block(float* W, int ldw, int R, int C, int i1, int count, int blocksize,
+                     const float* U, int ldu, const float* scale_tab, const float* zero_tab,
+                     int tab_ld, const int32_t* col_group, int bits, float* Err, uint8_t* codes,
+                     int ldc, const int32_t* col_map, float* loss, gptq_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Whole solve -- replaces GPTQ.fasterquant (gptq.py:126-305), default branch.
+ * W [R, C] fp32: in = layer weights (original column order), out = dequantized
+ * Q in original column order (gptq.py:300-305).  H [C, C] fp32 (upper triangle
+ * valid) is consumed and left holding the upper factor U (permuted order).
+ * scale_io/zero_io [R]: if preset != 0 they hold a ready grid (gptq.py:181);
+ * on return they hold the grid left in the quantizer (last one used).
+ * group_scale/group_zero (nullable, [R, n_groups]) receive the per-group grids
+ * (n_groups = ceil(C/groupsize)) when groupsize > 0.
+ * perm_out (nullable, int32[C]) receives the act-order permutation.
+ * codes (nullable, uint8 [R, C]) receives integer codes in original column order.
+ * error_out (device fp32[1]) receives sum(Losses) (gptq.py:294).
+ * info (device int32[1], nullable): non-zero if the Hessian was not positive definite.
+ * ------------------------------------------------------------------------- */
+size_t gptq_fasterquant_workspace_bytes(int R, int C, int blocksize, int groupsize, int actorder,
+                                        int static_groups);
+int gptq_fasterquant(float* W, int ldw, float* H, int ldh, int R, int C, int bits, int sym,
+                     int blocksize, float percdamp, int groupsize, int actorder, int static_groups,
+                     float* scale_io, float* zero_io, int preset, float* group_scale,
+                     float* group_zero, int32_t* perm_out, uint8_t* codes, float* error_out,
+                     int32_t* info, void* workspace, size_t workspace_bytes, gptq_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Bit packing -- replaces Quant3Linear.pack (quant.py:152-187) and the int4
+ * layout of Quant4Linear.__init__ (zeroShot/models/quant.py:176-185).
+ * weight: [out, in] row-major (dtype w_dtype, leading dimension ldw);
+ * scales [out] fp32; zeros [out] fp32 = zero*scale (quant.py:153);
+ * qweight: int32 [in/32*bits, out] (bits = 3: 96-bit little-endian stream per
+ * 32 codes; bits = 4: nibble i%8 of word i/8).  in % 32 == 0 (3-bit) / in % 8 == 0.
+ * gptq_pack_codes packs ready integer codes (uint8 [out, in]) instead.
+ * ------------------------------------------------------------------------- */
+int gptq_pack_weights(const void* weight, int w_dtype, int ldw, int out_features, int in_features,
+                      const float* scales, const float* zeros, int bits, int32_t* qweight,
+                      gptq_stream_t stream);
+int gptq_pack_codes(const uint8_t* codes, int ldc, int out_features, int in_features, int bits,
+                    int32_t* qweight, gptq_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Packed dequant mat-vec -- replaces quant_cuda.vecquant3matmul /
+ * vecquant3matmul_faster (quant_cuda.cpp:15-29, quant_cuda_kernel.cu:31-244):
+ *   mul[col] += sum_k (scales[col]*q[k,col] - zeros[col]) * vec[k]
+ * vec: [in] (vec_dtype GPTQ_F32, or GPTQ_F16 for the "faster" form); mat int32
+ * [height, width], height = in/32*bits, width = out; mul/scales/zeros fp32 [width].
+ * vecquant4matmul has no reference kernel (only the layout is pinned, see above).
+ * ------------------------------------------------------------------------- */
+int gptq_vecquant3matmul(const void* vec, int vec_dtype, const int32_t* mat, float* mul,
+                         const float* scales, const float* zeros, int height, int width,
+                         gptq_stream_t stream);
+int gptq_vecquant4matmul(const void* vec, int vec_dtype, const int32_t* mat, float* mul,
+                         const float* scales, const float* zeros, int height, int width,
+                         gptq_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPTQ_HIP_H */

@@ -127,13 +127,14 @@ def fasterquant(
     blocksize: int = 128, percdamp: float = 0.01, groupsize: int = -1,
     actorder: bool = False, static_groups: bool = False,
     scale: Optional[torch.Tensor] = None, zero: Optional[torch.Tensor] = None,
-    Hinv_override: Optional[torch.Tensor] = None,
+    Hinv_override: Optional[torch.Tensor] = None, trace: Optional[list] = None,
 ) -> FasterquantResult:
     """gptq.py:126-305, default (plain affine quantizer) branch.
 
     W [R,C] (any float dtype; cast to fp32, gptq.py:135), H [C,C] fp32 (consumed).
     ``scale``/``zero`` pre-set a "ready" quantizer (gptq.py:181).  ``Hinv_override``
-    replaces the factorization chain's output (test hook for bit-exact loop parity).
+    replaces the factorization chain's output (test hook for bit-exact loop parity);
+    ``trace`` (a list) receives the working weights at every block start.
     """
     maxq = 2 ** bits - 1                                          # quant.py:27
     W = W.clone().float()
@@ -181,6 +182,8 @@ def fasterquant(
     for i1 in range(0, C, blocksize):                             # gptq.py:191
         i2 = min(i1 + blocksize, C)
         n = i2 - i1
+        if trace is not None:       # test hook: the global working weights entering this block
+            trace.append(W.clone())
         W1 = W[:, i1:i2].clone()                                  # gptq.py:195-199
         Q1 = torch.zeros_like(W1)
         E1 = torch.zeros_like(W1)

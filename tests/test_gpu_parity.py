@@ -1,0 +1,490 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the reference-made goldens.
+
+Bars:
+  bit-exact  -- find_params, quantize, the in-block loop given identical (W1, Hinv1, grid), pack3/pack4;
+  tolerance  -- Hessian rel-Fro <= 1e-6; Hinv rel-Fro <= 1e-5; end-to-end Q rel-Fro <= 1e-3 with the
+                code-mismatch fraction reported; error scalar rel <= 1e-3; matvec rel <= 1e-5 (fp32 x)
+                / 1e-2 (fp16 x) against the fp64 formula.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    import gptq_amd
+    from gptq_amd import _lib
+    _lib.load()
+    return gptq_amd
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import gptq_oracle
+    return gptq_oracle
+
+
+def relfro(a, b):
+    a = a.double(); b = b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-300))
+
+
+def cuda(x, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(x)) if isinstance(x, np.ndarray) else x
+    t = t.cuda()
+    return t.to(dtype) if dtype is not None else t
+
+
+class _Lin(torch.nn.Module):
+    """minimal Linear stand-in with a settable weight dtype"""
+    def __init__(self, w):
+        super().__init__()
+        self.weight = torch.nn.Parameter(w, requires_grad=False)
+        self.bias = None
+
+
+def make_linear(w):
+    lin = torch.nn.Linear(w.shape[1], w.shape[0], bias=False, device=w.device, dtype=w.dtype)
+    lin.weight.data = w.clone()
+    return lin
+
+
+# ------------------------------------------------------------------ a2 Hessian
+def test_hessian_golden(G, hip_device):
+    g = load_golden("g1_add_batch")
+    C = g["X"].shape[-1]
+    lin = make_linear(torch.zeros(8, C, device=hip_device))
+    gp = G.GPTQ(lin)
+    for k in range(g["X"].shape[0]):
+        gp.add_batch(cuda(g["X"][k]), None)
+        H = gp.H.cpu()
+        assert torch.equal(H, H.t())
+        assert relfro(H, torch.from_numpy(g["H_after"][k])) <= 1e-6
+    assert gp.nsamples == int(g["nsamples"])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("C,S", [(128, 64), (200, 77), (130, 33), (384, 512)])
+def test_hessian_shapes_dtypes(G, O, hip_device, dtype, C, S):
+    gen = torch.Generator().manual_seed(C * 1000 + S)
+    lin = make_linear(torch.zeros(4, C, device=hip_device))
+    gp = G.GPTQ(lin)
+    Href = torch.zeros(C, C)
+    n = 0
+    for b in (1, 2):   # second call uses a batch of 2 samples (tmp = 2, gptq.py:44)
+        x = (torch.randn(b, S, C, generator=gen) * (1 + torch.arange(C) % 5)).to(dtype)
+        gp.add_batch(x.cuda(), None)
+        n = O.hessian_add_batch(Href, n, x)
+    assert gp.nsamples == n
+    # fp64 truth for an absolute yardstick too
+    assert relfro(gp.H.cpu(), Href) <= 1e-6
+
+
+def test_hessian_odd_leading_dimension(G, O, hip_device):
+    # a strided view with ld % 4 != 0 exercises the scalar load path
+    C, S = 130, 50
+    gen = torch.Generator().manual_seed(5)
+    big = torch.randn(S, C + 3, generator=gen).half()
+    x = big[:, :C]
+    gp = G.GPTQ(make_linear(torch.zeros(4, C, device=hip_device)))
+    xg = big.cuda()[:, :C]
+    assert xg.stride(0) == C + 3
+    gp.add_batch(xg, None)
+    Href = torch.zeros(C, C)
+    O.hessian_add_batch(Href, 0, x.contiguous())
+    assert relfro(gp.H.cpu(), Href) <= 1e-6
+
+
+# ------------------------------------------------------- a4 / a5 grids (bit-exact)
+@pytest.mark.parametrize("bits", [2, 3, 4, 8])
+@pytest.mark.parametrize("sym", [False, True])
+def test_find_params_quantize_bit_exact(G, bits, sym):
+    g = load_golden("g2_find_params")
+    W = cuda(g["W"])
+    q = G.Quantizer()
+    q.configure(bits, perchannel=True, sym=sym, mse=False)
+    assert not bool(q.ready())
+    q.find_params(W, weight=True)
+    tag = f"b{bits}_{'sym' if sym else 'asym'}"
+    assert np.array_equal(q.scale.cpu().numpy(), g[tag + "_scale"])
+    assert np.array_equal(q.zero.cpu().numpy(), g[tag + "_zero"])
+    out = G.quantize(W, q.scale, q.zero, q.maxq)
+    assert np.array_equal(out.cpu().numpy(), g[tag + "_q"])
+    assert bool(q.ready())
+
+
+def test_find_params_random_bit_exact(G, O):
+    gen = torch.Generator().manual_seed(11)
+    W = torch.randn(333, 1000, generator=gen) * 0.1
+    for sym in (False, True):
+        s, z = O.find_params(W, 15, sym)
+        q = G.Quantizer(); q.configure(4, perchannel=True, sym=sym, mse=False)
+        q.find_params(W.cuda(), weight=True)
+        assert torch.equal(q.scale.cpu(), s) and torch.equal(q.zero.cpu(), z)
+        assert torch.equal(G.quantize(W.cuda(), q.scale, q.zero, q.maxq).cpu(), O.quantize(W, s, z, 15))
+
+
+def test_out_of_scope_options_raise(G, hip_device):
+    q = G.Quantizer(); q.configure(4, perchannel=True, sym=False, mse=True)
+    with pytest.raises(NotImplementedError):
+        q.find_params(torch.zeros(4, 8, device=hip_device))
+    q = G.Quantizer(); q.configure(4, perchannel=True, sym=False, trits=True)
+    with pytest.raises(NotImplementedError):
+        q.find_params(torch.zeros(4, 8, device=hip_device))
+    gp = G.GPTQ(make_linear(torch.zeros(4, 32, device=hip_device)))
+    gp.quantizer = G.Quantizer(); gp.quantizer.configure(4, perchannel=True, sym=False)
+    for kw in ({"lut_quant": True}, {"non_linear_quant": True}, {"columnwise": True}):
+        with pytest.raises(NotImplementedError):
+            gp.fasterquant(**kw)
+
+
+# ------------------------------------------------------------ chain (tolerance)
+def _hinv_gpu(H, percdamp, perm=None):
+    from gptq_amd import _lib
+    lib = _lib.load()
+    C = H.shape[0]
+    Hg = H.clone().cuda().contiguous()
+    nb = lib.gptq_hinv_workspace_bytes(C)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    p = perm.to(torch.int32).cuda() if perm is not None else None
+    _lib.call("gptq_hinv_upper", _lib.ptr(Hg), Hg.stride(0), C, float(percdamp), _lib.ptr(p), _lib.ptr(info),
+              _lib.ptr(ws), nb, _lib.stream(Hg.device))
+    return Hg.cpu(), int(info.item())
+
+
+@pytest.mark.parametrize("name", ["g3_plain_c256", "g3_plain_c320", "g3_actorder", "g3_percdamp10", "g3_dead_col"])
+def test_hinv_upper_vs_reference(G, O, name):
+    g = load_golden(name)
+    H = torch.from_numpy(g["H"]).clone()
+    dead = torch.diag(H) == 0
+    H[dead, dead] = 1
+    perm = torch.argsort(torch.diag(H), descending=True) if bool(g["actorder"]) else None
+    U, info = _hinv_gpu(H, float(g["percdamp"]), perm)
+    assert info == 0
+    assert torch.equal(U, torch.triu(U))
+    Uref = torch.from_numpy(g["Hinv"])
+    assert relfro(U, Uref) <= 1e-5
+    # and against fp64 truth: ours must not be less accurate than the reference's own chain
+    Hd = H.double()
+    if perm is not None:
+        Hd = Hd[perm][:, perm]
+    Hd = Hd + torch.eye(H.shape[0], dtype=torch.float64) * float(g["percdamp"]) * torch.diag(Hd).mean()
+    truth = torch.linalg.cholesky(torch.linalg.inv(Hd), upper=True)
+    assert relfro(U, truth) <= max(2 * relfro(Uref, truth), 2e-6)
+
+
+def test_hinv_upper_mid_size_fp64(G):
+    gen = torch.Generator().manual_seed(7)
+    C = 1000     # not a multiple of 128: exercises the padded tail and 8 diagonal blocks
+    X = torch.randn(3000, C, generator=gen, dtype=torch.float64) * (1 + torch.arange(C) % 7)
+    H = (X.t() @ X * (2 / 3000)).float()
+    U, info = _hinv_gpu(H, 0.01)
+    assert info == 0
+    Hd = H.double() + torch.eye(C, dtype=torch.float64) * 0.01 * torch.diag(H.double()).mean()
+    truth = torch.linalg.cholesky(torch.linalg.inv(Hd), upper=True)
+    assert relfro(U, truth) <= 1e-5
+
+
+def test_hinv_not_positive_definite_raises(G, hip_device):
+    C = 256
+    H = -torch.eye(C)
+    _, info = _hinv_gpu(H, 0.0)
+    assert info != 0
+    gp = G.GPTQ(make_linear(torch.randn(8, C, device=hip_device)))
+    gp.quantizer = G.Quantizer(); gp.quantizer.configure(4, perchannel=True, sym=False)
+    gp.H = (-torch.eye(C)).to(hip_device)
+    with pytest.raises(torch.linalg.LinAlgError):
+        gp.fasterquant()
+
+
+# --------------------------------------------- in-block loop: bit-exact given Hinv1
+def _block_loop_gpu(Wblk_in, Hinv, i1, count, blocksize, stab, ztab, col_group, bits):
+    from gptq_amd import _lib
+    W = Wblk_in.clone().cuda().contiguous()
+    R, C = W.shape
+    U = Hinv.cuda().contiguous()
+    Err = torch.full((R, blocksize), float("nan"), device="cuda")
+    loss = torch.zeros(R, device="cuda")
+    codes = torch.zeros((R, C), dtype=torch.uint8, device="cuda")
+    st = stab.cuda().contiguous(); zt = ztab.cuda().contiguous()
+    cg = col_group.to(torch.int32).cuda() if col_group is not None else None
+    _lib.call("gptq_quant_block", _lib.ptr(W), W.stride(0), R, C, i1, count, blocksize, _lib.ptr(U), U.stride(0),
+              _lib.ptr(st), _lib.ptr(zt), st.shape[1], _lib.ptr(cg), bits, _lib.ptr(Err), _lib.ptr(codes), C,
+              None, _lib.ptr(loss), _lib.stream(W.device))
+    return W.cpu(), Err.cpu(), loss.cpu(), codes.cpu()
+
+
+@pytest.mark.parametrize("name", ["g3_plain_c256", "g3_plain_c320", "g3_plain_3bit", "g3_plain_sym", "g3_plain_2bit",
+                                  "g3_g128_static", "g3_g64_dyn", "g3_g32_dyn_sym", "g3_blocksize64", "g3_dead_col"])
+def test_block_loop_bit_exact(G, O, name):
+    """Every block, fed the oracle's working weights at block entry and the reference's Hinv, must
+    reproduce Q1 and the compensated in-block state bit for bit (gptq.py:201-271)."""
+    g = load_golden(name)
+    bits, sym, B = int(g["bits"]), bool(g["sym"]), int(g["blocksize"])
+    gs, static = int(g["groupsize"]), bool(g["static_groups"])
+    Hinv = torch.from_numpy(g["Hinv"])
+    trace = []
+    r = O.fasterquant(torch.from_numpy(g["W"]), torch.from_numpy(g["H"]), bits=bits, sym=sym, blocksize=B,
+                      percdamp=float(g["percdamp"]), groupsize=gs, actorder=False, static_groups=static,
+                      Hinv_override=Hinv, trace=trace)
+    assert np.array_equal(r.Q.numpy(), g["Q"])            # the override reproduces the reference run
+    R, C = g["W"].shape
+    if gs > 0:
+        ngr = -(-C // gs)
+        stab = torch.stack([r.col_scale[:, min(j * gs, C - 1)] for j in range(ngr)], 1)
+        ztab = torch.stack([r.col_zero[:, min(j * gs, C - 1)] for j in range(ngr)], 1)
+        cg = torch.arange(C) // gs
+    else:
+        stab, ztab, cg = r.col_scale[:, :1].clone(), r.col_zero[:, :1].clone(), None
+    for b, i1 in enumerate(range(0, C, B)):
+        count = min(B, C - i1)
+        Wout, Err, loss, codes = _block_loop_gpu(trace[b], Hinv, i1, count, B, stab, ztab, cg, bits)
+        assert torch.equal(Wout[:, i1:i1 + count], r.Q[:, i1:i1 + count]), f"block {b}"
+        assert torch.equal(codes[:, i1:i1 + count].int(), r.codes[:, i1:i1 + count]), f"block {b}"
+        # Err1 = (w - q) / d with the exact in-block w: check through the next block's entry weights
+        if i1 + count < C:
+            upd = trace[b][:, i1 + count:] - Err[:, :count] @ Hinv[i1:i1 + count, i1 + count:]
+            assert relfro(upd, trace[b + 1][:, i1 + count:]) <= 1e-6
+        assert torch.equal(Wout[:, :i1], trace[b][:, :i1]) and torch.equal(Wout[:, i1 + count:], trace[b][:, i1 + count:])
+        assert not torch.isnan(Err[:, :count]).any() and torch.all(Err[:, count:] == 0)
+
+
+# ---------------------------------------------------- a6 end-to-end (tolerance)
+def _run_gptq(G, W, H, n, *, bits, sym, dtype=torch.float32, **kw):
+    lin = make_linear(W.cuda().to(dtype))
+    gp = G.GPTQ(lin)
+    gp.H = H.clone().cuda()
+    gp.nsamples = n
+    gp.quantizer = G.Quantizer()
+    gp.quantizer.configure(bits, perchannel=True, sym=sym, mse=False)
+    gp.fasterquant(**kw)
+    return lin, gp
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names("g3_") if n != "g3_mid512"])
+def test_fasterquant_vs_reference_golden(G, name):
+    g = load_golden(name)
+    kw = dict(blocksize=int(g["blocksize"]), percdamp=float(g["percdamp"]), groupsize=int(g["groupsize"]),
+              actorder=bool(g["actorder"]), static_groups=bool(g["static_groups"]))
+    lin, gp = _run_gptq(G, torch.from_numpy(g["W"]), torch.from_numpy(g["H"]), 3, bits=int(g["bits"]),
+                        sym=bool(g["sym"]), **kw)
+    Q = lin.weight.data.cpu()
+    Qref = torch.from_numpy(g["Q"])
+    mismatch = float((Q != Qref).float().mean())
+    print(f"{name}: relFro {relfro(Q, Qref):.2e}, element mismatch {mismatch:.2e}, error {gp.error:.6g} vs {float(g['error']):.6g}")
+    assert relfro(Q, Qref) <= 1e-3
+    assert mismatch <= 2e-3
+    assert abs(gp.error - float(g["error"])) <= 1e-3 * abs(float(g["error"]))
+    # the grid left in the quantizer is order-independent arithmetic: exact unless it was derived
+    # from compensated weights (dynamic groups), where a flipped code upstream may move a min/max
+    sref, zref = torch.from_numpy(g["scale"]), torch.from_numpy(g["zero"])
+    if int(g["groupsize"]) == -1 or bool(g["static_groups"]):
+        assert torch.equal(gp.quantizer.scale.cpu(), sref) and torch.equal(gp.quantizer.zero.cpu(), zref)
+    else:
+        assert relfro(gp.quantizer.scale.cpu(), sref) <= 1e-3
+    # every output value sits exactly on its row's grid
+    codes = gp.codes.cpu().float()
+    assert codes.max() <= 2 ** int(g["bits"]) - 1
+
+
+def test_fasterquant_mid512_codes(G):
+    g = load_golden("g3_mid512")
+    lin, gp = _run_gptq(G, torch.from_numpy(g["W"]).float(), torch.from_numpy(g["H"]), 2, bits=4, sym=False)
+    codes = gp.codes.cpu()
+    frac = float((codes != torch.from_numpy(g["codes"])).float().mean())
+    print(f"mid512: code mismatch fraction {frac:.2e}")
+    assert frac <= 1e-3
+    assert relfro(lin.weight.data.cpu(), torch.from_numpy(g["Q"])) <= 1e-3
+    assert torch.equal(gp.quantizer.scale.cpu(), torch.from_numpy(g["scale"]))
+    # Q is exactly scale * (code - zero)
+    s, z = gp.quantizer.scale.cpu(), gp.quantizer.zero.cpu()
+    assert torch.equal(lin.weight.data.cpu(), s * (codes.float() - z))
+
+
+def test_fasterquant_fp16_layer_and_hessian_from_add_batch(G, O):
+    """The real calling sequence: fp16 layer, hooks feed add_batch, weights come back in fp16."""
+    g = load_golden("g3_mid512")
+    W16 = torch.from_numpy(g["W"])                    # fp16
+    lin = make_linear(W16.cuda())
+    gp = G.GPTQ(lin)
+    gp.quantizer = G.Quantizer(); gp.quantizer.configure(4, perchannel=True, sym=False, mse=False)
+    for k in range(g["X"].shape[0]):
+        gp.add_batch(cuda(g["X"][k]), None)
+    gp.fasterquant(blocksize=128, percdamp=0.01, groupsize=-1)
+    assert lin.weight.dtype == torch.float16
+    Qref = torch.from_numpy(g["Q"]).half()            # gptq.py:305 cast
+    frac = float((lin.weight.data.cpu() != Qref).float().mean())
+    assert frac <= 1e-3
+    gp.free()
+    assert gp.H is None
+
+
+# ----------------------------------------------------------------- a9 / a12 pack
+@pytest.mark.parametrize("bits", [3, 4])
+def test_pack_golden_bit_exact(G, bits):
+    g = load_golden("g4_pack")
+    tag = f"b{bits}_"
+    W = torch.from_numpy(g[tag + "W"])
+    R, C = W.shape
+    lin = torch.nn.Linear(C, R)                        # on the host, like opt_pack3 (opt.py:370)
+    lin.weight.data = W.clone(); lin.bias.data = torch.from_numpy(g[tag + "bias"])
+    m = (G.Quant3Linear if bits == 3 else G.Quant4Linear)(C, R)
+    m.pack(lin, torch.from_numpy(g[tag + "scale"]), torch.from_numpy(g[tag + "zero"]))
+    assert m.qweight.dtype == torch.int32
+    assert np.array_equal(m.qweight.numpy(), g[tag + "qweight"])
+    assert np.array_equal(m.zeros.numpy(), g[tag + "zeros_buf"])
+    assert np.array_equal(m.scales.numpy(), g[tag + "scales_buf"])
+    assert set(m.state_dict().keys()) == {"zeros", "scales", "bias", "qweight"}
+
+
+@pytest.mark.parametrize("bits", [3, 4])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("R,C", [(100, 160), (256, 1024), (70, 96)])
+def test_pack_random_bit_exact(G, O, bits, dtype, R, C):
+    gen = torch.Generator().manual_seed(R + C + bits)
+    W = (torch.randn(R, C, generator=gen) * 0.05)
+    s, z = O.find_params(W, 2 ** bits - 1, False)
+    Wq = O.quantize(W, s, z, 2 ** bits - 1).to(dtype)
+    iw = O.intweight(Wq, s, z)
+    ref = (O.pack3 if bits == 3 else O.pack4)(iw)
+    from gptq_amd.quant import _pack, pack_codes
+    got = _pack(Wq.cuda(), s.cuda(), (z * s).cuda(), bits).cpu().numpy()
+    assert np.array_equal(got, ref)
+    got2 = pack_codes(torch.from_numpy(iw.T.astype(np.uint8).copy()).cuda(), bits).cpu().numpy()
+    assert np.array_equal(got2, ref)
+
+
+def test_pack3_out_of_range_codes_wrap_like_numpy(G, O):
+    # weights far off the grid: the reference ORs overflowing uint32 codes into neighbours (quant.py:166-183)
+    gen = torch.Generator().manual_seed(3)
+    W = torch.randn(64, 96, generator=gen) * 3
+    s = torch.full((64, 1), 0.01); z = torch.full((64, 1), 4.0)
+    ref = O.pack3(O.intweight(W, s, z))
+    from gptq_amd.quant import _pack
+    got = _pack(W.cuda(), s.cuda(), (z * s).cuda(), 3).cpu().numpy()
+    assert np.array_equal(got, ref)
+
+
+# ---------------------------------------------------------------- a10 mat-vec
+@pytest.mark.parametrize("bits", [3, 4])
+@pytest.mark.parametrize("in_f,out_f", [(256, 256), (1024, 768), (2048, 1000), (96, 130), (4096, 4096)])
+def test_matvec_vs_fp64_formula(G, O, bits, in_f, out_f):
+    rng = np.random.default_rng(in_f + out_f + bits)
+    iw = rng.integers(0, 2 ** bits, size=(in_f, out_f), dtype=np.uint32)
+    qw = (O.pack3 if bits == 3 else O.pack4)(iw)
+    scales = (rng.random(out_f) * 0.02 + 0.001).astype(np.float32)
+    zeros = (rng.integers(0, 2 ** bits, size=out_f) * scales).astype(np.float32)
+    bias = rng.standard_normal(out_f).astype(np.float32)
+    x = rng.standard_normal(in_f).astype(np.float32)
+    ref = O.dequant_matvec(x, qw, bias, scales, zeros, bits)
+    from gptq_amd import quant_cuda
+    fn = quant_cuda.vecquant3matmul if bits == 3 else quant_cuda.vecquant4matmul
+    y = cuda(bias.copy())
+    fn(cuda(x), cuda(qw), y, cuda(scales).reshape(-1, 1), cuda(zeros).reshape(-1, 1))
+    denom = np.abs(ref).max()
+    assert np.abs(y.cpu().numpy().astype(np.float64) - ref).max() <= 1e-5 * denom
+    # fp16 activations ("faster" form)
+    y16 = cuda(bias.copy())
+    x16 = torch.from_numpy(x).half()
+    ref16 = O.dequant_matvec(x16.float().numpy(), qw, bias, scales, zeros, bits)
+    fn16 = quant_cuda.vecquant3matmul_faster if bits == 3 else quant_cuda.vecquant4matmul
+    fn16(x16.cuda(), cuda(qw), y16, cuda(scales).reshape(-1, 1), cuda(zeros).reshape(-1, 1))
+    assert np.abs(y16.cpu().numpy().astype(np.float64) - ref16).max() <= 1e-2 * denom
+
+
+def test_quant3linear_forward_and_errors(G, O, hip_device):
+    gen = torch.Generator().manual_seed(9)
+    R, C = 512, 1024
+    W = torch.randn(R, C, generator=gen) * 0.03
+    s, z = O.find_params(W, 7, False)
+    Wq = O.quantize(W, s, z, 7)
+    lin = torch.nn.Linear(C, R); lin.weight.data = Wq.half().float(); lin.bias.data = torch.randn(R, generator=gen)
+    for faster in (False, True):
+        m = G.Quant3Linear(C, R, faster=faster)
+        m.pack(lin, s, z)
+        m = m.to(hip_device)
+        x = torch.randn(1, 1, C, generator=gen)
+        y = m(x.to(hip_device))
+        assert y.shape == (1, 1, R)
+        ref = lin(x)
+        assert relfro(y.cpu(), ref) <= (5e-3 if faster else 1e-4)
+        with pytest.raises(ValueError, match="single token"):
+            m(torch.zeros(2, C, device=hip_device))
+    model = torch.nn.Sequential()
+    model.add_module("fc", torch.nn.Linear(64, 32))
+    G.make_quant3(model, ["fc"])
+    assert isinstance(model.fc, G.Quant3Linear) and model.fc.qweight.shape == (6, 32)
+
+
+# ------------------------------------------ BASELINE-size, size-independent properties
+def test_full_size_properties_opt1p3b_fc1(G, hip_device):
+    """OPT-1.3b fc1 (8192 x 2048), 4-bit, groupsize 128 static (BASELINE configs[1])."""
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    R, C, S = 8192, 2048, 2048
+    W = (torch.randn(R, C, device=hip_device, generator=gen) * 0.02).half()
+    lin = make_linear(W)
+    gp = G.GPTQ(lin)
+    gp.quantizer = G.Quantizer(); gp.quantizer.configure(4, perchannel=True, sym=False, mse=False)
+    chan = (1 + torch.arange(C, device=hip_device) % 7).half()
+    for j in range(4):
+        x = torch.randn(1, S, C, device=hip_device, generator=gen).half() * chan
+        gp.add_batch(x, None)
+    H = gp.H.clone()
+    assert torch.equal(H, H.t())
+    gp.fasterquant(blocksize=128, percdamp=0.01, groupsize=128, static_groups=True)
+    codes, gs, gz = gp.codes, gp.group_scale, gp.group_zero
+    assert int(codes.max()) <= 15
+    # on-grid: the fp32 Q is exactly scale*(code - zero) of the column's group (then cast to fp16)
+    grp = torch.arange(C, device=hip_device) // 128
+    Qgrid = gs[:, grp] * (codes.float() - gz[:, grp])
+    assert torch.equal(lin.weight.data, Qgrid.half())
+    # U^T U (H + damp I) = I  in fp64
+    U = gp.Hinv.double()
+    Hd = H.double() + torch.eye(C, device=hip_device, dtype=torch.float64) * 0.01 * torch.diag(H.double()).mean()
+    resid = (U.t() @ U @ Hd - torch.eye(C, device=hip_device, dtype=torch.float64)).norm() / math.sqrt(C)
+    assert float(resid) <= 1e-4
+    # GPTQ beats round-to-nearest on the layer-output proxy  tr((W-Q) H (W-Q)^T)
+    Wf = W.float()
+    rtn = torch.empty_like(Wf)
+    for j in range(C // 128):
+        q = G.Quantizer(); q.configure(4, perchannel=True, sym=False, mse=False)
+        blk = Wf[:, 128 * j:128 * (j + 1)].contiguous()
+        q.find_params(blk, weight=True)
+        rtn[:, 128 * j:128 * (j + 1)] = G.quantize(blk, q.scale, q.zero, q.maxq)
+    def proxy(Q):
+        D = (Wf - Q.float()).double()
+        return float(((D @ H.double()) * D).sum())
+    assert proxy(lin.weight.data) < 0.8 * proxy(rtn)
+
+
+def test_full_size_pack_matvec_roundtrip(G, O, hip_device):
+    """FC2-like shape of the kernel benchmark, scaled to finish quickly on the CPU side: pack ->
+    matvec linearity and agreement with a dense fp32 GEMV of the dequantized weights."""
+    in_f, out_f = 9216, 4096
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    codes = torch.randint(0, 8, (out_f, in_f), device=hip_device, generator=gen, dtype=torch.uint8)
+    qw = G.pack_codes(codes, 3)
+    assert qw.shape == (in_f // 32 * 3, out_f)
+    scales = torch.rand(out_f, 1, device=hip_device, generator=gen) * 0.01 + 1e-3
+    zeros = torch.randint(0, 8, (out_f, 1), device=hip_device, generator=gen).float() * scales
+    from gptq_amd import quant_cuda
+    x1 = torch.randn(in_f, device=hip_device, generator=gen)
+    x2 = torch.randn(in_f, device=hip_device, generator=gen)
+    def mv(x):
+        y = torch.zeros(out_f, device=hip_device)
+        quant_cuda.vecquant3matmul(x, qw, y, scales, zeros)
+        return y
+    Wd = scales * codes.float() - zeros
+    assert relfro(mv(x1).cpu(), (Wd.double() @ x1.double()).cpu()) <= 1e-5
+    assert relfro(mv(x1 + 2 * x2).cpu(), (mv(x1) + 2 * mv(x2)).cpu()) <= 1e-5
+    # unpack on the host agrees with the codes we packed
+    back = O.unpack3(qw[:96].cpu().numpy())
+    assert np.array_equal(back, codes[:, :1024].t().cpu().numpy().astype(np.uint32))
