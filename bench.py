@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mparams/s quantized (4-bit) on BASELINE.json configs[1].
+
+A step = one pass of the GPTQ hot path over one OPT-1.3b decoder block's six Linears
+(q,k,v,out 2048x2048, fc1 8192x2048, fc2 2048x8192; 4-bit, groupsize 128, static groups as
+opt.py:584-587 forces), exactly as the reference drives it for one block (opt.py:177-214):
+  1. Hessian accumulation: nsamples x add_batch per Linear (one 2048-token sample per call, fp16);
+  2. fasterquant per Linear (damped inverse factor + column loop + trailing updates);
+  3. 4-bit pack of the integer codes (the reference packs on the host; its own TODO, opt.py:361).
+Inputs (fp16 weights + fp16 calibration activations) are resident in HBM before the timed
+region.  value = params quantized by all ranks / max-over-ranks wall time.
+
+N > 1 (one process per GPU, launched by torch.distributed.run): weak scaling -- the job is N
+blocks' worth of Linears dealt to ranks by cost (gptq_amd.parallel.assign_units); the only
+exchange is the all-gather of packed weights + grids at the step boundary (RCCL over xGMI).
+
+Besides the contract keys the JSON line carries
+  roofline      -- dominant kernel (the fp32-MFMA Hessian SYRK): algorithmic flops / measured
+                   kernel time against the 157.3 TFLOP/s dense fp32 matrix peak;
+  cpu_baseline  -- the oracle (reference algorithm, torch CPU fp32) timed on this box's host
+                   cores on a bounded sample of the same workload (rank 0, N = 1 only);
+  phases        -- per-phase milliseconds and the solve-only Mparams/s (the scope the reference's
+                   own timer prints, gptq.py:139-293).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+SHAPES = [("q_proj", 2048, 2048), ("k_proj", 2048, 2048), ("v_proj", 2048, 2048), ("out_proj", 2048, 2048),
+          ("fc1", 8192, 2048), ("fc2", 2048, 8192)]
+BITS, GROUPSIZE, SEQLEN = 4, 128, 2048
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, dense fp32 matrix peak
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nsamples", type=int, default=128, help="calibration samples per step (reference default 128)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-samples", type=int, default=128, help="calibration samples in the CPU baseline sample")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import gptq_amd
+    import gptq_amd.gptq as gmod
+    from gptq_amd import parallel as par
+    from gptq_amd import _lib
+    _lib.load()
+    gmod.VERBOSE = False
+
+    # ---- unit list: `world` blocks' worth of Linears, dealt by cost -----------------------------
+    units = [par.Unit(f"b{b}.{n}", r, c) for b in range(world) for (n, r, c) in SHAPES]
+    costs = [par.unit_cost(u, args.nsamples, SEQLEN) for u in units]
+    assignment = par.assign_units(costs, world)
+    mine = assignment[rank]
+    total_params = sum(u.params for u in units)
+
+    # ---- synthetic inputs, resident in HBM (W ~ N(0, 0.02^2), X ~ N(0,1)*(1 + c mod 7)) ----
+    gen = torch.Generator(device=dev).manual_seed(1000 + rank)
+    weights = {i: (torch.randn(units[i].rows, units[i].cols, device=dev, generator=gen) * 0.02).half() for i in mine}
+    acts = {}
+    for C in sorted({units[i].cols for i in mine}):
+        chan = (1 + torch.arange(C, device=dev) % 7).half()
+        acts[C] = torch.randn(args.nsamples, SEQLEN, C, device=dev, generator=gen, dtype=torch.float16) * chan
+    torch.cuda.synchronize()
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    phase_ms = {"hessian": 0.0, "solve": 0.0, "pack": 0.0, "allgather": 0.0}
+    hess_flops = 0.0
+    hess_launches = 0
+
+    def step(record):
+        nonlocal hess_flops, hess_launches
+        packed = {}
+        for i in mine:
+            u = units[i]
+            lin = torch.nn.Linear(u.cols, u.rows, bias=False, device=dev, dtype=torch.float16)
+            lin.weight.data = weights[i].clone()
+            g = gptq_amd.GPTQ(lin)
+            g.quantizer = gptq_amd.Quantizer()
+            g.quantizer.configure(BITS, perchannel=True, sym=False, mse=False)
+            X = acts[u.cols]
+            e0, e1, e2, e3 = ev(), ev(), ev(), ev()
+            e0.record()
+            for j in range(args.nsamples):                       # opt.py:184-185 -> hook -> add_batch
+                g.add_batch(X[j:j + 1], None)
+            e1.record()
+            g.fasterquant(blocksize=128, percdamp=0.01, groupsize=GROUPSIZE, actorder=False, static_groups=True)
+            e2.record()
+            q = gptq_amd.pack_codes(g.codes, BITS)
+            e3.record()
+            packed[i] = (q, g.group_scale, g.group_zero)
+            g.free()
+            if record:
+                torch.cuda.synchronize()
+                phase_ms["hessian"] += e0.elapsed_time(e1)
+                phase_ms["solve"] += e1.elapsed_time(e2)
+                phase_ms["pack"] += e2.elapsed_time(e3)
+                hess_flops += args.nsamples * float(SEQLEN) * u.cols * u.cols   # upper-triangle SYRK: S*C^2
+                hess_launches += args.nsamples
+        if world > 1:
+            a0, a1 = ev(), ev()
+            a0.record()
+            par.allgather_packed(packed, units, assignment, BITS, GROUPSIZE)
+            a1.record()
+            if record:
+                torch.cuda.synchronize()
+                phase_ms["allgather"] += a0.elapsed_time(a1)
+        return packed
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total_params / (elapsed / args.steps) / 1e6
+
+    out = {
+        "metric": "Mparams/sec quantized (4bit)", "value": round(value, 2), "unit": "Mparams/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "OPT-1.3b decoder block (BASELINE configs[1]): q,k,v,out 2048x2048, fc1 8192x2048, "
+                               "fc2 2048x8192; 4-bit asym, groupsize 128 (static groups), blocksize 128, percdamp 0.01",
+                   "nsamples": args.nsamples, "seqlen": SEQLEN, "blocks_per_step": world,
+                   "scope": "add_batch x nsamples + fasterquant + 4-bit pack for every Linear",
+                   "parallelism": "1 GPU" if world == 1 else f"module-sharded over {world} GPUs, all-gather of packed weights"},
+    }
+    if rank == 0:
+        steps = args.steps
+        hess_s = phase_ms["hessian"] / 1e3
+        achieved = hess_flops / hess_s / 1e12 if hess_s > 0 else 0.0
+        out["roofline"] = {
+            "kernel": "hessian_kernel<__half> (fp32-MFMA SYRK, upper triangle)", "bound": "mfma",
+            "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "algorithmic_flops_per_launch": "S*C^2 (tokens x C^2, symmetric half)",
+            "avg_launch_ms": round(phase_ms["hessian"] / max(hess_launches, 1), 4), "launches": hess_launches,
+        }
+        solve_ms = (phase_ms["solve"] + phase_ms["pack"]) / steps
+        rank_params = sum(units[i].params for i in mine)
+        out["phases"] = {k: round(v / steps, 3) for k, v in phase_ms.items()}
+        out["phases"]["solve_only_mparams_per_s"] = round(rank_params / (solve_ms / 1e3) / 1e6, 1) if solve_ms > 0 else None
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_samples)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(nsamples):
+    """The oracle (the reference's algorithm restated on torch CPU fp32, bit-identical to the
+    reference on the golden vectors) on ONE q_proj-shaped Linear of the same workload:
+    nsamples x add_batch (2048 tokens each) + fasterquant (4-bit, g128 static) + pack."""
+    from oracle import gptq_oracle as O
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    R = C = 2048
+    gen = torch.Generator().manual_seed(0)
+    W = (torch.randn(R, C, generator=gen) * 0.02).half()
+    chan = (1 + torch.arange(C) % 7).float()
+    x = (torch.randn(1, SEQLEN, C, generator=gen) * chan).half()
+    H = torch.zeros(C, C)
+    t0 = time.perf_counter()
+    n = 0
+    for _ in range(nsamples):
+        n = O.hessian_add_batch(H, n, x)
+    t1 = time.perf_counter()
+    r = O.fasterquant(W, H, bits=BITS, sym=False, blocksize=128, percdamp=0.01, groupsize=GROUPSIZE,
+                      actorder=False, static_groups=True)
+    t2 = time.perf_counter()
+    O.pack4(r.codes.t().contiguous().numpy().astype("uint32"))
+    t3 = time.perf_counter()
+    total = t3 - t0
+    return {"value": round(R * C / total / 1e6, 4), "unit": "Mparams/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"one q_proj-shaped Linear ({R}x{C}) of the workload: {nsamples} x add_batch (2048 tokens) "
+                      f"+ fasterquant (4-bit, g128 static) + pack; {total:.1f} s "
+                      f"(hessian {t1 - t0:.1f} s, solve {t2 - t1:.1f} s, pack {t3 - t2:.1f} s)",
+            "solve_only_mparams_per_s": round(R * C / (t2 - t1) / 1e6, 3)}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,95 @@
+"""Module-level sharding of one transformer block's Linears across the GPUs of a node.
+
+The reference has no distributed code; this is the capability BASELINE
+config 5 / north_star adds: the Linears hooked in one forward pass are independent GPTQ
+problems (opt.py:189-214 walks them serially only for convenience), so they are dealt to
+ranks by cost and the only exchange is an all-gather of the PACKED weights (+ grids) at the
+block boundary -- every rank needs them to run the post-quantization forward (opt.py:216-217).
+One process per GPU, torch.distributed ("nccl" = RCCL over xGMI on ROCm; "gloo" on CPU in tests).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+@dataclass(frozen=True)
+class Unit:
+    """One Linear to quantize: `name`, out_features R, in_features C."""
+    name: str
+    rows: int
+    cols: int
+
+    @property
+    def params(self) -> int:
+        return self.rows * self.cols
+
+
+def unit_cost(u: Unit, nsamples: int, seqlen: int, blocksize: int = 128) -> float:
+    """fp32 flop model of the path for one Linear: Hessian SYRK (upper half)
+    + factorization chain (2/3 C^3 here) + trailing updates (R C^2) + in-block rank-1 updates."""
+    R, C = u.rows, u.cols
+    return nsamples * seqlen * C * C + (2.0 / 3.0) * C ** 3 + R * C * C + R * C * blocksize
+
+
+def assign_units(costs: Sequence[float], world: int) -> List[List[int]]:
+    """Longest-processing-time-first: returns, per rank, the indices of its units (deterministic)."""
+    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+    load = [0.0] * world
+    out: List[List[int]] = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        out[r].append(i)
+        load[r] += costs[i]
+    return out
+
+
+def packed_shapes(u: Unit, bits: int, groupsize: int) -> Tuple[Tuple[int, int], Tuple[int, int]]:
+    """(qweight shape, grid-table shape) of a packed Linear."""
+    groups = 1 if groupsize <= 0 else -(-u.cols // groupsize)
+    return (u.cols // 32 * bits, u.rows), (u.rows, groups)
+
+
+def allgather_packed(local: Dict[int, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]], units: Sequence[Unit],
+                     assignment: Sequence[Sequence[int]], bits: int, groupsize: int,
+                     group=None) -> Dict[int, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
+    """Every rank contributes (qweight int32, scales fp32, zeros fp32) for the units it owns and
+    receives everybody's.  One fixed-size all-gather: each rank's tensors are flattened into a
+    single int32 buffer padded to the largest rank payload (shapes are known to all ranks from
+    `assignment`, so no size exchange is needed)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+
+    def payload(idx_list):
+        n = 0
+        for i in idx_list:
+            (qh, qw), (gr, gc) = packed_shapes(units[i], bits, groupsize)
+            n += qh * qw + 2 * gr * gc
+        return n
+
+    sizes = [payload(a) for a in assignment]
+    width = max(max(sizes), 1)
+    some = next(iter(local.values()))[0] if local else None
+    device = some.device if some is not None else torch.device("cpu")
+    send = torch.zeros(width, dtype=torch.int32, device=device)
+    off = 0
+    for i in assignment[rank]:
+        q, s, z = local[i]
+        for t in (q.reshape(-1), s.reshape(-1).float().view(torch.int32), z.reshape(-1).float().view(torch.int32)):
+            send[off:off + t.numel()] = t
+            off += t.numel()
+    recv = torch.empty(world * width, dtype=torch.int32, device=device)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    out: Dict[int, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = {}
+    for r in range(world):
+        off = r * width
+        for i in assignment[r]:
+            (qh, qw), (gr, gc) = packed_shapes(units[i], bits, groupsize)
+            q = recv[off:off + qh * qw].reshape(qh, qw); off += qh * qw
+            s = recv[off:off + gr * gc].view(torch.float32).reshape(gr, gc); off += gr * gc
+            z = recv[off:off + gr * gc].view(torch.float32).reshape(gr, gc); off += gr * gc
+            out[i] = (q, s, z)
+    return out

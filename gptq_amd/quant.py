@@ -149,7 +149,7 @@ class _QuantLinearBase(nn.Module):
         self.zeros = (zeros.to(dev) * scales).to(home)
         self.scales = scales.clone().to(home)
         if linear.bias is not None:
-            self.bias = linear.bias.clone()
+            self.bias = linear.bias.detach().clone()
         qweight = _pack(linear.weight.data.to(dev), scales, self.zeros.to(dev), self.bits)
         self.qweight = qweight.to(home)
 

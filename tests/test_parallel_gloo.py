@@ -1,0 +1,76 @@
+"""Module-sharding host logic on CPU: LPT assignment + the packed-weight all-gather over gloo (world 2)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gptq_amd import parallel as par
+
+
+def test_lpt_assignment_balances_and_is_deterministic():
+    units = [par.Unit(n, r, c) for b in range(2) for (n, r, c) in
+             [("q", 2048, 2048), ("k", 2048, 2048), ("v", 2048, 2048), ("o", 2048, 2048), ("fc1", 8192, 2048), ("fc2", 2048, 8192)]]
+    costs = [par.unit_cost(u, 128, 2048) for u in units]
+    a = par.assign_units(costs, 2)
+    assert a == par.assign_units(costs, 2)
+    assert sorted(i for r in a for i in r) == list(range(len(units)))
+    loads = [sum(costs[i] for i in r) for r in a]
+    assert max(loads) / min(loads) < 1.05
+    one = par.assign_units(costs, 1)
+    assert sorted(one[0]) == list(range(len(units)))
+    # more ranks than units: the surplus ranks stay empty
+    a8 = par.assign_units(costs[:3], 8)
+    assert sum(len(r) for r in a8) == 3 and max(len(r) for r in a8) == 1
+
+
+def test_cost_model_orders_the_opt_shapes():
+    c_q = par.unit_cost(par.Unit("q", 2048, 2048), 128, 2048)
+    c_fc1 = par.unit_cost(par.Unit("fc1", 8192, 2048), 128, 2048)
+    c_fc2 = par.unit_cost(par.Unit("fc2", 2048, 8192), 128, 2048)
+    assert c_q < c_fc1 < c_fc2
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        units = [par.Unit("a", 64, 96), par.Unit("b", 32, 64), par.Unit("c", 128, 256), par.Unit("d", 16, 32)]
+        costs = [par.unit_cost(u, 4, 16) for u in units]
+        assignment = par.assign_units(costs, world)
+        bits, gs = 4, 32
+
+        def fake(i):
+            (qh, qw), (gr, gc) = par.packed_shapes(units[i], bits, gs)
+            g = torch.Generator().manual_seed(100 + i)
+            q = torch.randint(-2 ** 31, 2 ** 31 - 1, (qh, qw), generator=g, dtype=torch.int64).to(torch.int32)
+            return q, torch.rand(gr, gc, generator=g), torch.rand(gr, gc, generator=g)
+
+        local = {i: fake(i) for i in assignment[rank]}
+        everything = par.allgather_packed(local, units, assignment, bits, gs)
+        ok = sorted(everything) == list(range(len(units)))
+        for i in range(len(units)):
+            q, s, z = fake(i)
+            gq, gs_, gz = everything[i]
+            ok = ok and torch.equal(gq, q) and torch.equal(gs_, s) and torch.equal(gz, z)
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_allgather_packed_world2_gloo():
+    world = 2
+    port = _free_port()
+    with mp.Manager() as m:
+        ret = m.dict()
+        mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+        assert dict(ret) == {0: True, 1: True}
