@@ -41,6 +41,10 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, dense fp32 matrix peak
 PEAK_HBM_GBS = 8000.0
 
 
+def log(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,6 +140,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if rank == 0:
+        log(f"inputs resident; {len(mine)} Linears on rank 0; warmup {args.warmup}, steps {args.steps}")
     for _ in range(args.warmup):
         step(False)
     barrier()
@@ -149,6 +155,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    if rank == 0:
+        log(f"timed region done: {elapsed:.3f} s for {args.steps} steps")
     ms_per_step = elapsed / args.steps * 1e3
     value = total_params / (elapsed / args.steps) / 1e6
 
@@ -189,7 +197,9 @@ def cpu_baseline(nsamples):
     reference on the golden vectors) on ONE q_proj-shaped Linear of the same workload:
     nsamples x add_batch (2048 tokens each) + fasterquant (4-bit, g128 static) + pack."""
     from oracle import gptq_oracle as O
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    # the box's CPU share, not the host's core count (oversubscribing MKL stalls for minutes)
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    log(f"cpu baseline: {nsamples} x add_batch + fasterquant on {torch.get_num_threads()} threads ...")
     R = C = 2048
     gen = torch.Generator().manual_seed(0)
     W = (torch.randn(R, C, generator=gen) * 0.02).half()
@@ -198,8 +208,10 @@ def cpu_baseline(nsamples):
     H = torch.zeros(C, C)
     t0 = time.perf_counter()
     n = 0
-    for _ in range(nsamples):
+    for k in range(nsamples):
         n = O.hessian_add_batch(H, n, x)
+        if k % 32 == 31:
+            log(f"cpu baseline: add_batch {k + 1}/{nsamples} at {time.perf_counter() - t0:.1f} s")
     t1 = time.perf_counter()
     r = O.fasterquant(W, H, bits=BITS, sym=False, blocksize=128, percdamp=0.01, groupsize=GROUPSIZE,
                       actorder=False, static_groups=True)

@@ -103,8 +103,13 @@ def run_fasterquant(lin, H, n, bits, sym, **kw):
     g.nsamples = n
     g.quantizer = ref_quant.Quantizer()
     g.quantizer.configure(bits, perchannel=True, sym=sym, mse=False)
-    grabbed = {}
+    grabbed = {"grids": []}
     real_chol = torch.linalg.cholesky
+    real_quantize = ref_gptq.quantize
+
+    def quantize_spy(x, scale, zero, maxq):        # gptq.py:262-264: one call per column, in loop order
+        grabbed["grids"].append((scale.clone().flatten(), zero.clone().flatten()))
+        return real_quantize(x, scale, zero, maxq)
 
     def spy(a, *args, upper=False, **kwargs):
         r = real_chol(a, *args, upper=upper, **kwargs)
@@ -113,19 +118,33 @@ def run_fasterquant(lin, H, n, bits, sym, **kw):
         return r
 
     torch.linalg.cholesky = spy
+    ref_gptq.quantize = quantize_spy
     buf = io.StringIO()
     try:
         with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
             g.fasterquant(**kw)
     finally:
         torch.linalg.cholesky = real_chol
+        ref_gptq.quantize = real_quantize
     err = None
     for line in buf.getvalue().splitlines():
         if line.startswith("error"):
             err = float(line.split()[1])
-    return dict(Q=lin.weight.data.clone().numpy(), scale=g.quantizer.scale.clone().numpy(),
+    Q = lin.weight.data.clone()
+    # per-column grids in PROCESSING order -> original column order, and the integer codes
+    cs = torch.stack([a for a, _ in grabbed["grids"]], 1)
+    cz = torch.stack([b for _, b in grabbed["grids"]], 1)
+    if kw.get("actorder"):
+        dead = torch.diag(H) == 0
+        Hd = H.clone(); Hd[dead, dead] = 1
+        perm = torch.argsort(torch.diag(Hd), descending=True)      # gptq.py:166 on the same input
+        inv = torch.argsort(perm)
+        cs, cz = cs[:, inv], cz[:, inv]
+    codes = torch.clamp(torch.round(Q / cs) + cz, 0, 2 ** bits - 1).to(torch.uint8)
+    assert torch.equal(cs * (codes.float() - cz), Q)
+    return dict(Q=Q.numpy(), scale=g.quantizer.scale.clone().numpy(),
                 zero=g.quantizer.zero.clone().numpy(), error=np.float64(err),
-                Hinv=grabbed["Hinv"].numpy())
+                Hinv=grabbed["Hinv"].numpy(), col_scale=cs.numpy(), col_zero=cz.numpy(), codes=codes.numpy())
 
 
 def hessian_for(gen, C, S, n, dead=()):
@@ -187,8 +206,7 @@ def g3():
         xs.append(x.numpy())
     res = run_fasterquant(lin, g.H.clone(), g.nsamples, 4, False, blocksize=128, percdamp=0.01,
                           groupsize=-1, actorder=False, static_groups=False)
-    codes = np.clip(np.round(res["Q"] / res["scale"]) + res["zero"], 0, 15).astype(np.uint8)
-    save("g3_mid512", W=w.half().numpy(), X=np.stack(xs), H=g.H.numpy(), codes=codes,
+    save("g3_mid512", W=w.half().numpy(), X=np.stack(xs), H=g.H.numpy(), codes=res["codes"],
          scale=res["scale"], zero=res["zero"], error=res["error"], Q=res["Q"].astype(np.float32),
          bits=np.int64(4), sym=np.bool_(False))
 

@@ -46,6 +46,9 @@ def test_g3_fasterquant_bit_exact(name):
     assert np.array_equal(r.scale.numpy(), g["scale"])
     assert np.array_equal(r.zero.numpy(), g["zero"])
     assert r.error == float(g["error"])
+    assert np.array_equal(r.col_scale.numpy(), g["col_scale"])
+    assert np.array_equal(r.col_zero.numpy(), g["col_zero"])
+    assert np.array_equal(r.codes.numpy().astype(np.uint8), g["codes"])
 
 
 def test_g3_mid512_bit_exact():
