@@ -72,39 +72,68 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
   constexpr int LD = NB + 1;
   __shared__ float S[NB * LD];
   __shared__ float rdiag[NB];
-  __shared__ float ddiag[NB];
+  __shared__ float colbuf[2][NB];
   const int tid = threadIdx.x;
   float* Ak = A + (long)kb * NB * Cp + (long)kb * NB;
 
-  for (int idx = tid; idx < NB * NB; idx += 512) {
-    const int i = idx >> 7, k = idx & 127;
-    S[i * LD + k] = (k <= i) ? Ak[(long)i * Cp + k] : 0.f;
-  }
+  // ---- factorization, register resident: thread (iy = tid >> 5, kx = tid & 31) owns the elements
+  //      (i = iy + 16a, k = kx + 32b), a < 8, b < 4, of the lower triangle.  Per column j the owners
+  //      publish the raw column through LDS (double buffered -> ONE barrier per column), every thread
+  //      scales the entries it needs by 1/sqrt(a_jj) and applies its share of the rank-1 update.
   const int kx = tid & 31, iy = tid >> 5;
-  for (int j = 0; j < NB; ++j) {
-    __syncthreads();
-    // S[j][j] keeps the pivot a_jj (its square root goes to ddiag) so that every thread can
-    // read it here without a third barrier per column.
-    const float ajj = S[j * LD + j];
-    const float d = sqrtf(ajj);
-    if (tid > j && tid < NB) S[tid * LD + j] = S[tid * LD + j] / d;
-    if (tid == j) {
-      ddiag[j] = d;
-      rdiag[j] = 1.f / d;
-      if (!(ajj > 0.f) && info) atomicCAS(info, 0, kb * NB + j + 1);
+  float a[8][4];
+#pragma unroll
+  for (int aa = 0; aa < 8; ++aa)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int i = iy + 16 * aa, k = kx + 32 * b;
+      a[aa][b] = (k <= i) ? Ak[(long)i * Cp + k] : 0.f;
     }
-    __syncthreads();
-    for (int i = j + 1 + iy; i < NB; i += 16) {
-      const float li = S[i * LD + j];
-      for (int k = j + 1 + kx; k <= i; k += 32) S[i * LD + k] -= li * S[k * LD + j];
+#pragma unroll
+  for (int bj = 0; bj < 4; ++bj) {
+#pragma unroll 1
+    for (int jl = 0; jl < 32; ++jl) {
+      const int j = 32 * bj + jl;
+      float* cb = colbuf[j & 1];
+      if (kx == jl) {
+#pragma unroll
+        for (int aa = 0; aa < 8; ++aa) cb[iy + 16 * aa] = a[aa][bj];   // rows < j carry zeros / stale, unused
+      }
+      __syncthreads();
+      const float ajj = cb[j];
+      const float d = sqrtf(ajj);
+      const float inv = 1.f / d;
+      if (tid == 0) {
+        rdiag[j] = inv;
+        if (!(ajj > 0.f) && info) atomicCAS(info, 0, kb * NB + j + 1);
+      }
+      float li[8], lk[4];
+#pragma unroll
+      for (int aa = 0; aa < 8; ++aa) li[aa] = cb[iy + 16 * aa] * inv;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) lk[b] = cb[kx + 32 * b] * inv;
+#pragma unroll
+      for (int aa = 0; aa < 8; ++aa) {
+        const int i = iy + 16 * aa;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int k = kx + 32 * b;
+          if (k > j && k <= i) a[aa][b] -= li[aa] * lk[b];
+        }
+        if (kx == jl) a[aa][bj] = (i > j) ? li[aa] : ((i == j) ? d : a[aa][bj]);   // column j is final
+      }
     }
   }
+  // L_kk -> LDS (for the inverse) and back to A (kept for inspection)
+#pragma unroll
+  for (int aa = 0; aa < 8; ++aa)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int i = iy + 16 * aa, k = kx + 32 * b;
+      S[i * LD + k] = (k <= i) ? a[aa][b] : 0.f;
+      if (k <= i) Ak[(long)i * Cp + k] = a[aa][b];
+    }
   __syncthreads();
-  // write L_kk back (kept for inspection; later stages only use the inverse and the panels)
-  for (int idx = tid; idx < NB * NB; idx += 512) {
-    const int i = idx >> 7, k = idx & 127;
-    if (k <= i) Ak[(long)i * Cp + k] = (k == i) ? ddiag[i] : S[i * LD + k];
-  }
 
   // ---- inverse: thread (c = tid >> 2, q = tid & 3) owns rows i = 4r + q of column c ----
   const int c = tid >> 2, q = tid & 3;

@@ -218,6 +218,19 @@ __global__ __launch_bounds__(256) void quant_block_kernel(QuantBlockArgs a) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) { e[t] = 0.f; cd[t] = 0.f; }
 
+    // grids of this phase's 32 columns: lane c fetches those of columns 4t + c up front (all loads in
+    // flight together, off the sequential chain) and the quad shares them by DPP at each step
+    float psc[8], pzr[8];
+    if (GROUPED) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int col = 32 * ph + 4 * t + c;
+        const int g = grp[min(col, B - 1)];
+        psc[t] = (active && col < a.count) ? a.scale_tab[rbase * a.tab_ld + g] : 1.f;
+        pzr[t] = (active && col < a.count) ? a.zero_tab[rbase * a.tab_ld + g] : 0.f;
+      }
+    }
+
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       float cur[4];
@@ -225,16 +238,19 @@ __global__ __launch_bounds__(256) void quant_block_kernel(QuantBlockArgs a) {
       cur[1] = quad_bcast<1>(w[t]);
       cur[2] = quad_bcast<2>(w[t]);
       cur[3] = quad_bcast<3>(w[t]);
+      float gs4[4], gz4[4];
+      if (GROUPED) {
+        gs4[0] = quad_bcast<0>(psc[t]); gs4[1] = quad_bcast<1>(psc[t]);
+        gs4[2] = quad_bcast<2>(psc[t]); gs4[3] = quad_bcast<3>(psc[t]);
+        gz4[0] = quad_bcast<0>(pzr[t]); gz4[1] = quad_bcast<1>(pzr[t]);
+        gz4[2] = quad_bcast<2>(pzr[t]); gz4[3] = quad_bcast<3>(pzr[t]);
+      }
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) {
         const int il = 4 * t + cc;
         const int i = 32 * ph + il;
         if (i < a.count) {                                       // block-uniform
-          if (GROUPED) {
-            const int g = grp[i];
-            sc = active ? a.scale_tab[rbase * a.tab_ld + g] : 1.f;
-            zr = active ? a.zero_tab[rbase * a.tab_ld + g] : 0.f;
-          }
+          if (GROUPED) { sc = gs4[cc]; zr = gz4[cc]; }
           const float* urow = Us + il * 4 * LDCL;
           const float x = cur[cc];
           const float code = affine_code(x, sc, zr, a.maxq);     // gptq.py:262-264

@@ -31,6 +31,150 @@ __global__ __launch_bounds__(GEMM_THREADS) void hessian_kernel(float* __restrict
   });
 }
 
+// ---------------------------------------------------------------------------------------------
+// fp16 / bf16 activations: the products x_si * x_sj of two 11-bit (8-bit) significands are EXACT in
+// fp32, so the 16x-faster f16/bf16 MFMA with fp32 accumulation loses nothing against the reference's
+// fp32 matmul of the widened inputs (gptq.py:62-65) -- it only rounds the running sum, like any fp32
+// GEMM does.  The 2/n scaling is applied once per element in the epilogue.
+//
+// 128x128 tile, BK = 64 tokens per stage, v_mfma_f32_32x32x16_{f16,bf16}.  X tiles sit in LDS exactly
+// as in HBM ([token][channel], channel contiguous); the MFMA wants 8 consecutive k (tokens) per lane,
+// which is what ds_read_b64_tr_b16 (gfx950's transposing LDS read) delivers: per 16-lane group a
+// 4-token x 16-channel block, column-major.  Row stride 320 B puts the 4 rows x 2 groups of a half-wave
+// on 8 disjoint 32-byte bank slots (conflict-free).
+// ---------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int HBK = 64;                 // tokens per stage
+constexpr int HROW = 160;               // LDS row stride in 16-bit elements (128 + 32 pad = 320 B)
+constexpr int HTILE = HBK * HROW;       // elements per operand stage
+
+template <bool BF16>
+__device__ __forceinline__ f32x16 mfma16(s16x8 a, s16x8 b, f32x16 c) {
+  if (BF16) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// this thread's 4 x 16-byte pieces of a [HBK tokens][128 channels] slab starting at token k0
+__device__ __forceinline__ void h16_load(const unsigned short* __restrict__ X, long ldx, int rem, bool vec,
+                                         int k0, int tokens, uint4 r[4]) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int v = tid + 256 * e;
+    const int row = v >> 4, c8 = (v & 15) * 8;
+    const int k = k0 + row;
+    const unsigned short* p = X + (long)k * ldx + c8;
+    if (k < tokens && vec && c8 + 8 <= rem) {
+      r[e] = *reinterpret_cast<const uint4*>(p);
+    } else {
+      unsigned short t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] = (k < tokens && c8 + j < rem) ? p[j] : (unsigned short)0;
+      r[e] = make_uint4(t[0] | (t[1] << 16), t[2] | (t[3] << 16), t[4] | (t[5] << 16), t[6] | (t[7] << 16));
+    }
+  }
+}
+
+__device__ __forceinline__ void h16_store(unsigned short* S, const uint4 r[4]) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int v = tid + 256 * e;
+    *reinterpret_cast<uint4*>(S + (v >> 4) * HROW + (v & 15) * 8) = r[e];
+  }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void hessian16_kernel(float* __restrict__ H, int ldh,
+                                                        const unsigned short* __restrict__ X, int ldx, int C,
+                                                        int tokens, float alpha, float beta, bool vec) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short hsm[];   // [2 buffers][A, B][HTILE]
+  const int nt = (C + GBM - 1) / GBM;
+  int rest = blockIdx.x, ti = 0;
+  while (rest >= nt - ti) { rest -= nt - ti; ++ti; }
+  const int tj = ti + rest;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int rem_a = min(GBM, C - ti * GBM), rem_b = min(GBN, C - tj * GBN);
+  const unsigned short* Xa = X + (long)ti * GBM;
+  const unsigned short* Xb = X + (long)tj * GBN;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // transposed-read address of this lane inside a 16-token k-step: row 8h + q, channel 16g + 4p
+  const int h = lane >> 5, g = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
+  const int frag_off = (8 * h + q) * HROW + 16 * g + 4 * p;
+
+  uint4 ra[4], rb[4];
+  const int nk = (tokens + HBK - 1) / HBK;
+  h16_load(Xa, ldx, rem_a, vec, 0, tokens, ra);
+  h16_load(Xb, ldx, rem_b, vec, 0, tokens, rb);
+  h16_store(hsm, ra);
+  h16_store(hsm + HTILE, rb);
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) {
+      h16_load(Xa, ldx, rem_a, vec, (kt + 1) * HBK, tokens, ra);
+      h16_load(Xb, ldx, rem_b, vec, (kt + 1) * HBK, tokens, rb);
+    }
+    const unsigned short* As = hsm + cur * 2 * HTILE + wm * 64 + frag_off;
+    const unsigned short* Bs = hsm + cur * 2 * HTILE + HTILE + wn * 64 + frag_off;
+#pragma unroll
+    for (int kk = 0; kk < HBK / 16; ++kk) {
+      s16x8 fa[2], fb[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const unsigned short* pa = As + kk * 16 * HROW + t * 32;
+        const unsigned short* pb = Bs + kk * 16 * HROW + t * 32;
+        const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa));
+        const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa + 4 * HROW));
+        const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pb));
+        const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pb + 4 * HROW));
+        fa[t] = s16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        fb[t] = s16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+      }
+      acc[0][0] = mfma16<BF16>(fa[0], fb[0], acc[0][0]);
+      acc[0][1] = mfma16<BF16>(fa[0], fb[1], acc[0][1]);
+      acc[1][0] = mfma16<BF16>(fa[1], fb[0], acc[1][0]);
+      acc[1][1] = mfma16<BF16>(fa[1], fb[1], acc[1][1]);
+    }
+    if (more) {
+      h16_store(hsm + (cur ^ 1) * 2 * HTILE, ra);
+      h16_store(hsm + (cur ^ 1) * 2 * HTILE + HTILE, rb);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  float* Ht = H + (long)ti * GBM * ldh + (long)tj * GBN;
+  const bool diag = ti == tj;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        const int col = wn * 64 + j * 32 + (lane & 31);
+        if (row < rem_a && col < rem_b && !(diag && row > col)) {
+          float* hp = Ht + (long)row * ldh + col;
+          *hp = alpha * *hp + beta * acc[i][j][e];
+        }
+      }
+}
+
 // A[r][c] = A[c][r] for r > c, through a 32x33 LDS tile so both sides stay coalesced.
 __global__ __launch_bounds__(256) void symmetrize_kernel(float* __restrict__ A, int lda, int n) {
   __shared__ float t[32][33];
@@ -71,14 +215,18 @@ extern "C" int gptq_hessian_accum(float* H, int ldh, const void* X, int x_dtype,
       hessian_kernel<float><<<blocks, GEMM_THREADS, 0, s>>>(H, ldh, x, ldx, C, tokens, alpha, beta, vec_ok(x, ldx));
       break;
     }
-    case GPTQ_F16: {
-      const __half* x = static_cast<const __half*>(X);
-      hessian_kernel<__half><<<blocks, GEMM_THREADS, 0, s>>>(H, ldh, x, ldx, C, tokens, alpha, beta, vec_ok(x, ldx));
-      break;
-    }
+    case GPTQ_F16:
     case GPTQ_BF16: {
-      const __hip_bfloat16* x = static_cast<const __hip_bfloat16*>(X);
-      hessian_kernel<__hip_bfloat16><<<blocks, GEMM_THREADS, 0, s>>>(H, ldh, x, ldx, C, tokens, alpha, beta, vec_ok(x, ldx));
+      const unsigned short* x = static_cast<const unsigned short*>(X);
+      const bool vec = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (ldx % 8 == 0);
+      const size_t lds = sizeof(unsigned short) * 4 * HTILE;
+      if (x_dtype == GPTQ_F16) {
+        GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hessian16_kernel<false><<<blocks, 256, lds, s>>>(H, ldh, x, ldx, C, tokens, alpha, beta, vec);
+      } else {
+        GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hessian16_kernel<true><<<blocks, 256, lds, s>>>(H, ldh, x, ldx, C, tokens, alpha, beta, vec);
+      }
       break;
     }
     default:

@@ -505,3 +505,41 @@ def test_full_size_pack_matvec_roundtrip(G, O, hip_device):
     # unpack on the host agrees with the codes we packed
     back = O.unpack3(qw[:96].cpu().numpy())
     assert np.array_equal(back, codes[:, :1024].t().cpu().numpy().astype(np.uint32))
+
+
+# ------------------------------------------- f16/bf16 MFMA Hessian: exact products, fp32 accumulate
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_hessian_16bit_mfma_precision_full_sequence(G, O, hip_device, dtype):
+    """2048-token samples (BASELINE seqlen): the f16/bf16-MFMA path must be at least as close to fp64
+    truth as the reference's own fp32 matmul of the widened inputs (gptq.py:62-65)."""
+    gen = torch.Generator().manual_seed(17)
+    C, S = 512, 2048
+    chan = 1 + torch.arange(C) % 7
+    gp = G.GPTQ(make_linear(torch.zeros(4, C, device=hip_device)))
+    Href = torch.zeros(C, C)
+    truth = torch.zeros(C, C, dtype=torch.float64)
+    n = 0
+    for k in range(3):
+        x = (torch.randn(1, S, C, generator=gen) * chan).to(dtype)
+        if k == 1:
+            x[0, :, 7] = x[0, :, 7] * 1e-4          # a nearly-dead channel
+            x[0, 5, :] = 0                          # an all-zero token
+        gp.add_batch(x.cuda(), None)
+        xd = x.double().reshape(-1, C)
+        truth = truth * (n / (n + 1)) + (2 / (n + 1)) * (xd.t() @ xd)
+        n = O.hessian_add_batch(Href, n, x)
+    ours, ref = relfro(gp.H.cpu(), truth), relfro(Href, truth)
+    print(f"{dtype}: ours vs fp64 {ours:.2e}, reference fp32 vs fp64 {ref:.2e}")
+    assert ours <= max(1e-6, 2 * ref)
+    assert relfro(gp.H.cpu(), Href) <= 2e-6
+
+
+def test_hessian_fp16_subnormal_inputs_are_not_flushed(G, hip_device):
+    C, S = 128, 64
+    x = torch.full((1, S, C), 2.0 ** -20, dtype=torch.float16)     # fp16 subnormal (min normal is 2^-14)
+    assert float(x[0, 0, 0]) > 0
+    gp = G.GPTQ(make_linear(torch.zeros(4, C, device=hip_device)))
+    gp.add_batch(x.cuda(), None)
+    expect = 2.0 * S * (2.0 ** -40)
+    got = gp.H.cpu()
+    assert torch.allclose(got, torch.full_like(got, expect), rtol=1e-6, atol=0)
