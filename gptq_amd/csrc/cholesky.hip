@@ -89,6 +89,9 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
       const int i = iy + 16 * aa, k = kx + 32 * b;
       a[aa][b] = (k <= i) ? Ak[(long)i * Cp + k] : 0.f;
     }
+  // Only the column operand is masked (k > j).  Elements strictly above the diagonal are never read
+  // back, so they may collect garbage; whole row / column groups that lie left of or above the
+  // current column are skipped statically (the j loop is unrolled over its 32-column phase bj).
 #pragma unroll
   for (int bj = 0; bj < 4; ++bj) {
 #pragma unroll 1
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
       float* cb = colbuf[j & 1];
       if (kx == jl) {
 #pragma unroll
-        for (int aa = 0; aa < 8; ++aa) cb[iy + 16 * aa] = a[aa][bj];   // rows < j carry zeros / stale, unused
+        for (int aa = 2 * bj; aa < 8; ++aa) cb[iy + 16 * aa] = a[aa][bj];
       }
       __syncthreads();
       const float ajj = cb[j];
@@ -109,18 +112,20 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
       }
       float li[8], lk[4];
 #pragma unroll
-      for (int aa = 0; aa < 8; ++aa) li[aa] = cb[iy + 16 * aa] * inv;
+      for (int aa = 2 * bj; aa < 8; ++aa) li[aa] = cb[iy + 16 * aa] * inv;
 #pragma unroll
-      for (int b = 0; b < 4; ++b) lk[b] = cb[kx + 32 * b] * inv;
+      for (int b = bj; b < 4; ++b) lk[b] = cb[kx + 32 * b] * inv;
+      if (kx <= jl) lk[bj] = 0.f;                                   // k <= j: column already final
 #pragma unroll
-      for (int aa = 0; aa < 8; ++aa) {
-        const int i = iy + 16 * aa;
+      for (int aa = 2 * bj; aa < 8; ++aa) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const int k = kx + 32 * b;
-          if (k > j && k <= i) a[aa][b] -= li[aa] * lk[b];
+        for (int b = bj; b < 4; ++b) {
+          if (32 * b <= 16 * aa + 15) a[aa][b] -= li[aa] * lk[b];   // static: tile touches the lower triangle
         }
-        if (kx == jl) a[aa][bj] = (i > j) ? li[aa] : ((i == j) ? d : a[aa][bj]);   // column j is final
+        if (kx == jl) {
+          const int i = iy + 16 * aa;
+          a[aa][bj] = (i > j) ? li[aa] : ((i == j) ? d : a[aa][bj]);   // column j is final
+        }
       }
     }
   }

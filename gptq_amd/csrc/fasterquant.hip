@@ -201,14 +201,16 @@ __global__ __launch_bounds__(256) void quant_block_kernel(QuantBlockArgs a) {
   }
   float loss = 0.f;
 
-#pragma unroll 1
-  for (int ph = 0; ph < NPH; ++ph) {
+#pragma unroll
+  for (int ph = 0; ph < NPH; ++ph) {      // fully unrolled: the register slide below is pure renaming
     __syncthreads();
     // stage the 32 U rows of this phase: Us[il][k & 3][k >> 2] = U[i][k], k >= i (upper), else 0
     for (int idx = tid; idx < 32 * B; idx += 256) {
       const int il = idx / B, k = idx % B;
       const int i = 32 * ph + il;
-      float v = 0.f;
+      // columns past `count` (tail block) are padded: zero weights, identity U rows and a unit grid
+      // make their steps exact no-ops, so the hot loop below carries no `count` branches
+      float v = (k == i) ? 1.f : 0.f;
       if (i < a.count && k >= i && k < a.count) v = a.U[(long)(a.i1 + i) * a.ldu + a.i1 + k];
       Us[(il * 4 + (k & 3)) * LDCL + (k >> 2)] = v;
     }
@@ -230,6 +232,7 @@ __global__ __launch_bounds__(256) void quant_block_kernel(QuantBlockArgs a) {
         pzr[t] = (active && col < a.count) ? a.zero_tab[rbase * a.tab_ld + g] : 0.f;
       }
     }
+    const bool tail = !GROUPED && (32 * ph + 32 > a.count);   // block-uniform, false except in a tail block
 
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
@@ -248,30 +251,28 @@ __global__ __launch_bounds__(256) void quant_block_kernel(QuantBlockArgs a) {
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) {
         const int il = 4 * t + cc;
-        const int i = 32 * ph + il;
-        if (i < a.count) {                                       // block-uniform
-          if (GROUPED) { sc = gs4[cc]; zr = gz4[cc]; }
-          const float* urow = Us + il * 4 * LDCL;
-          const float x = cur[cc];
-          const float code = affine_code(x, sc, zr, a.maxq);     // gptq.py:262-264
-          const float q = sc * (code - zr);
-          const float d = urow[cc * LDCL + 8 * ph + t];          // Hinv1[i, i]
-          const float diff = x - q;
-          const float err = diff / d;                            // gptq.py:269
-          loss += (diff * diff) / (d * d);                       // gptq.py:267
-          if (c == cc) { w[t] = q; e[t] = err; cd[t] = code; }
+        float gsc = sc, gzr = zr;
+        if (GROUPED) { gsc = gs4[cc]; gzr = gz4[cc]; }
+        else if (tail && 32 * ph + il >= a.count) { gsc = 1.f; gzr = 0.f; }
+        const float* urow = Us + il * 4 * LDCL;
+        const float x = cur[cc];
+        const float code = affine_code(x, gsc, gzr, a.maxq);     // gptq.py:262-264
+        const float q = gsc * (code - gzr);
+        const float d = urow[cc * LDCL + 8 * ph + t];            // Hinv1[i, i]
+        const float err = (x - q) / d;                           // gptq.py:269
+        loss += err * err;                                       // (w-q)^2/d^2, gptq.py:267 (tolerance-level)
+        if (c == cc) { w[t] = q; e[t] = err; cd[t] = code; }
 #pragma unroll
-          for (int c2 = cc + 1; c2 < 4; ++c2)                    // rest of this super-step (uniform)
-            cur[c2] -= err * urow[c2 * LDCL + 8 * ph + t];       // gptq.py:270
-          const float* ul = urow + c * LDCL + 8 * ph;
+        for (int c2 = cc + 1; c2 < 4; ++c2)                      // rest of this super-step (uniform)
+          cur[c2] -= err * urow[c2 * LDCL + 8 * ph + t];         // gptq.py:270
+        const float* ul = urow + c * LDCL + 8 * ph;
 #pragma unroll
-          for (int t2 = t + 1; t2 < 8; ++t2) w[t2] -= err * ul[t2];
+        for (int t2 = t + 1; t2 < 8; ++t2) w[t2] -= err * ul[t2];
 #pragma unroll
-          for (int g = 1; g < NPH; ++g) {
-            if (ph + g < NPH) {                                  // block-uniform
+        for (int g = 1; g < NPH; ++g) {
+          if (ph + g < NPH) {                                    // block-uniform
 #pragma unroll
-              for (int t2 = 0; t2 < 8; ++t2) w[8 * g + t2] -= err * ul[8 * g + t2];
-            }
+            for (int t2 = 0; t2 < 8; ++t2) w[8 * g + t2] -= err * ul[8 * g + t2];
           }
         }
       }

@@ -88,15 +88,47 @@ __device__ __forceinline__ void h16_store(unsigned short* S, const uint4 r[4]) {
   }
 }
 
+// Upper-triangle tile (ti <= tj) for workgroup `bid`, chosen so that the tiles running together on
+// one XCD share operand panels in that XCD's L2.  Workgroups are dealt round-robin to the 8 XCDs
+// (bid % 8 labels the XCD group; speed only, never correctness); each group gets a contiguous run of
+// a supertile-ordered enumeration (8 x 8 tiles per supertile, diagonal supertiles triangular).
+__device__ __forceinline__ void hessian_tile_of(int bid, int nt, int& ti, int& tj) {
+  constexpr int SUP = 8;
+  const int T = nt * (nt + 1) / 2;
+  const int xcd = bid & 7, q = T >> 3, r = T & 7;
+  int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  int si = 0, rows = min(SUP, nt);
+  for (;; ++si) {
+    rows = min(SUP, nt - si * SUP);
+    const int cnt = rows * (rows + 1) / 2 + rows * (nt - si * SUP - rows);
+    if (v < cnt) break;
+    v -= cnt;
+  }
+  const int dcnt = rows * (rows + 1) / 2;
+  if (v < dcnt) {
+    int rr = 0;
+    while (v >= rows - rr) { v -= rows - rr; ++rr; }
+    ti = si * SUP + rr;
+    tj = ti + v;
+  } else {
+    v -= dcnt;
+    const int sjo = v / (rows * SUP);
+    const int col0 = (si + 1 + sjo) * SUP;
+    const int cols = min(SUP, nt - col0);
+    const int rem = v - sjo * rows * SUP;
+    ti = si * SUP + rem / cols;
+    tj = col0 + rem % cols;
+  }
+}
+
 template <bool BF16>
 __global__ __launch_bounds__(256) void hessian16_kernel(float* __restrict__ H, int ldh,
                                                         const unsigned short* __restrict__ X, int ldx, int C,
                                                         int tokens, float alpha, float beta, bool vec) {
   extern __shared__ __attribute__((aligned(16))) unsigned short hsm[];   // [2 buffers][A, B][HTILE]
   const int nt = (C + GBM - 1) / GBM;
-  int rest = blockIdx.x, ti = 0;
-  while (rest >= nt - ti) { rest -= nt - ti; ++ti; }
-  const int tj = ti + rest;
+  int ti, tj;
+  hessian_tile_of(blockIdx.x, nt, ti, tj);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int rem_a = min(GBM, C - ti * GBM), rem_b = min(GBN, C - tj * GBN);
