@@ -15,8 +15,9 @@ blocks' worth of Linears dealt to ranks by cost (gptq_amd.parallel.assign_units)
 exchange is the all-gather of packed weights + grids at the step boundary (RCCL over xGMI).
 
 Besides the contract keys the JSON line carries
-  roofline      -- dominant kernel (the fp32-MFMA Hessian SYRK): algorithmic flops / measured
-                   kernel time against the 157.3 TFLOP/s dense fp32 matrix peak;
+  roofline      -- dominant kernel (the f16-MFMA Hessian SYRK, fp32 accumulate): algorithmic flops
+                   (S*C^2 per launch, the symmetric half) / measured kernel time against the 2.5 PFLOP/s
+                   dense f16 MFMA peak;
   cpu_baseline  -- the oracle (reference algorithm, torch CPU fp32) timed on this box's host
                    cores on a bounded sample of the same workload (rank 0, N = 1 only);
   phases        -- per-phase milliseconds and the solve-only Mparams/s (the scope the reference's
@@ -37,7 +38,7 @@ import torch.distributed as dist
 SHAPES = [("q_proj", 2048, 2048), ("k_proj", 2048, 2048), ("v_proj", 2048, 2048), ("out_proj", 2048, 2048),
           ("fc1", 8192, 2048), ("fc2", 2048, 8192)]
 BITS, GROUPSIZE, SEQLEN = 4, 128, 2048
-PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, dense fp32 matrix peak
+PEAK_F16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md, dense f16/bf16 MFMA peak (the Hessian's products are exact in fp32)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -175,9 +176,9 @@ def main():
         hess_s = phase_ms["hessian"] / 1e3
         achieved = hess_flops / hess_s / 1e12 if hess_s > 0 else 0.0
         out["roofline"] = {
-            "kernel": "hessian_kernel<__half> (fp32-MFMA SYRK, upper triangle)", "bound": "mfma",
-            "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "kernel": "hessian16_kernel<f16> (v_mfma_f32_32x32x16_f16 SYRK, upper triangle, fp32 accumulate)", "bound": "mfma",
+            "achieved": round(achieved, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4), "traffic": None,
             "algorithmic_flops_per_launch": "S*C^2 (tokens x C^2, symmetric half)",
             "avg_launch_ms": round(phase_ms["hessian"] / max(hess_launches, 1), 4), "launches": hess_launches,
         }

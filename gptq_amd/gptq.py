@@ -24,6 +24,9 @@ from .quant import *  # noqa: F401,F403  (the reference's gptq.py re-exports qua
 
 DEBUG = False
 VERBOSE = True   # the reference prints `time` / `error` per layer (gptq.py:293-294)
+# The fork stores `self.input = mean(scaled batch)` in add_batch (gptq.py:63); only its out-of-scope
+# `analyse` / non_linear branches read it.  It costs an extra pass over X per call, so it is opt-in.
+TRACK_INPUT_MEAN = False
 
 
 class GPTQ:
@@ -87,8 +90,8 @@ class GPTQ:
                       x.stride(0), self.columns, x.shape[0], int(self.nsamples), int(batch), _lib.stream(self.dev))
         self._lower_stale = True
         self.nsamples += batch
-        # fork addition (gptq.py:63): token mean of the scaled batch; not used by the default branch
-        self.input = x.mean(0, dtype=torch.float32) * math.sqrt(2 / self.nsamples)
+        if TRACK_INPUT_MEAN:   # fork addition (gptq.py:63), unused by the default branch
+            self.input = x.mean(0, dtype=torch.float32) * math.sqrt(2 / self.nsamples)
 
     def fasterquant(self, blocksize=128, percdamp=.01, groupsize=-1, actorder=False, static_groups=False,
                     model_name="opt", layer_name="layer", lut_quant=False, non_linear_quant=False,
