@@ -207,6 +207,147 @@ __global__ __launch_bounds__(256) void hessian16_kernel(float* __restrict__ H, i
       }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Deep-prefetch variant for aligned shapes (tokens % 64 == 0, C % 128 == 0, 16-byte aligned rows).
+// The register-staged kernel above keeps ONE stage in flight, which leaves every 64-token stage
+// exposed to HBM / Infinity-Cache latency (measured: ~3.9K cycles per stage against 512 cycles of
+// MFMA).  Here X streams global -> LDS with LDS-DMA (global_load_lds_dwordx4, no VGPRs) into a ring of
+// RING stages, three stages ahead of the matrix cores; counted `s_waitcnt vmcnt(N)` + one raw
+// s_barrier per stage.
+//
+// LDS image per operand stage: 64 token rows x 256 B, unpadded (an LDS-DMA wave-instruction writes 1 KiB
+// contiguously = 4 rows), XOR-swizzled in 16-byte chunks: physical chunk = logical ^ ((row & 3) << 2).
+// The swizzle lives on the per-lane SOURCE address of the DMA and on the transposed read, and makes
+// ds_read_b64_tr_b16 conflict-free: the 4 rows x 4 chunks a half-wave touches land on 16 distinct chunks.
+// ---------------------------------------------------------------------------------------------
+constexpr int RING = 4;
+constexpr int DSTAGE = 2 * HBK * 256;        // bytes per ring slot: A + B, 64 rows x 256 B each
+
+__device__ __forceinline__ void dma_stage(const unsigned short* __restrict__ Xa, const unsigned short* __restrict__ Xb,
+                                          long ldx, int k0, char* slot, int wave, int lane) {
+  // wave w moves token rows [16w, 16w+16) of both operands: 4 + 4 one-KiB pieces
+  const int rl = lane >> 4;                                   // row inside the 4-row piece
+  const int chunk = (lane & 15) ^ (rl << 2);                  // logical 16-byte chunk this lane fetches
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int r = 16 * wave + 4 * u;
+    const long goff = (long)(k0 + r + rl) * ldx + 8 * chunk;
+    char* dst = slot + r * 256;                               // wave-uniform; the DMA adds lane * 16
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Xa + goff),
+                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Xb + goff),
+                                     (__attribute__((address_space(3))) void*)(dst + HBK * 256), 16, 0, 0);
+  }
+}
+
+typedef s16x4 frag_t;
+__device__ __forceinline__ s16x8 join8(frag_t lo, frag_t hi) {
+  return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+// one transposed 4-token x 16-channel read; OFF is an immediate byte offset
+#define TR_READ(dst, addr, OFF) \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF))
+// the 8 reads of k-step KK: A tile 0 (rows +0, +4), A tile 1, B tile 0, B tile 1
+#define TR_READ_STEP(F, KK)                         \
+  do {                                              \
+    TR_READ(F[0], aa0, (KK) * 4096);                \
+    TR_READ(F[1], aa0, (KK) * 4096 + 1024);         \
+    TR_READ(F[2], aa1, (KK) * 4096);                \
+    TR_READ(F[3], aa1, (KK) * 4096 + 1024);         \
+    TR_READ(F[4], ab0, (KK) * 4096);                \
+    TR_READ(F[5], ab0, (KK) * 4096 + 1024);         \
+    TR_READ(F[6], ab1, (KK) * 4096);                \
+    TR_READ(F[7], ab1, (KK) * 4096 + 1024);         \
+  } while (0)
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void hessian16_dma_kernel(float* __restrict__ H, int ldh,
+                                                            const unsigned short* __restrict__ X, int ldx, int C,
+                                                            int tokens, float alpha, float beta) {
+  extern __shared__ __attribute__((aligned(1024))) char ring[];          // RING x DSTAGE, the ONLY LDS object
+  const int nt = C / GBM;
+  int ti, tj;
+  hessian_tile_of(blockIdx.x, nt, ti, tj);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const unsigned short* Xa = X + (long)ti * GBM;
+  const unsigned short* Xb = X + (long)tj * GBN;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // per-lane byte offsets of the transposed reads (row 8h + q of a 16-token k-step, m/n-tile t)
+  const int h = lane >> 5, g = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
+  int offa[2], offb[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int ca = 8 * wm + 4 * t + 2 * g + (p >> 1), cb = 8 * wn + 4 * t + 2 * g + (p >> 1);
+    offa[t] = (8 * h + q) * 256 + 16 * (ca ^ (q << 2)) + 8 * (p & 1);
+    offb[t] = (8 * h + q) * 256 + 16 * (cb ^ (q << 2)) + 8 * (p & 1) + HBK * 256;
+  }
+
+  const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)ring);
+  const int nk = tokens / HBK;
+#pragma unroll
+  for (int st = 0; st < RING - 1; ++st)
+    if (st < nk) dma_stage(Xa, Xb, ldx, st * HBK, ring + st * DSTAGE, wave, lane);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int ahead = min(RING - 2, nk - 1 - kt);             // stages issued after stage kt (uniform)
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                             // stage kt landed for all waves; slot (kt-1)%RING is free
+    if (kt + RING - 1 < nk)
+      dma_stage(Xa, Xb, ldx, (kt + RING - 1) * HBK, ring + ((kt + RING - 1) % RING) * DSTAGE, wave, lane);
+    // Fragment reads go through inline asm: hipcc treats every LDS read as aliasing the in-flight
+    // LDS-DMA and would drain it with vmcnt(0).  We order them ourselves: the counted vmcnt + barrier
+    // above cover the DMA, lgkmcnt(0) + sched_barrier cover the reads (the MFMAs are register-only and
+    // would otherwise be hoisted above the wait).  Reads of k-step kk+1 fly under the MFMAs of kk.
+    const unsigned sbase = lds0 + (kt % RING) * DSTAGE;
+    const unsigned aa0 = sbase + offa[0], aa1 = sbase + offa[1], ab0 = sbase + offb[0], ab1 = sbase + offb[1];
+    frag_t f[2][8];
+    TR_READ_STEP(f[0], 0);
+#pragma unroll
+    for (int kk = 0; kk < HBK / 16; ++kk) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (kk == 0) { TR_READ_STEP(f[1], 1); }
+      else if (kk == 1) { TR_READ_STEP(f[0], 2); }
+      else if (kk == 2) { TR_READ_STEP(f[1], 3); }
+      const frag_t* c = f[kk & 1];
+      const s16x8 fa0 = join8(c[0], c[1]), fa1 = join8(c[2], c[3]);
+      const s16x8 fb0 = join8(c[4], c[5]), fb1 = join8(c[6], c[7]);
+      acc[0][0] = mfma16<BF16>(fa0, fb0, acc[0][0]);
+      acc[0][1] = mfma16<BF16>(fa0, fb1, acc[0][1]);
+      acc[1][0] = mfma16<BF16>(fa1, fb0, acc[1][0]);
+      acc[1][1] = mfma16<BF16>(fa1, fb1, acc[1][1]);
+    }
+  }
+
+  float* Ht = H + (long)ti * GBM * ldh + (long)tj * GBN;
+  const bool diag = ti == tj;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        const int col = wn * 64 + j * 32 + (lane & 31);
+        if (!(diag && row > col)) {
+          float* hp = Ht + (long)row * ldh + col;
+          *hp = alpha * *hp + beta * acc[i][j][e];
+        }
+      }
+}
+
 // A[r][c] = A[c][r] for r > c, through a 32x33 LDS tile so both sides stay coalesced.
 __global__ __launch_bounds__(256) void symmetrize_kernel(float* __restrict__ A, int lda, int n) {
   __shared__ float t[32][33];
@@ -251,6 +392,18 @@ extern "C" int gptq_hessian_accum(float* H, int ldh, const void* X, int x_dtype,
     case GPTQ_BF16: {
       const unsigned short* x = static_cast<const unsigned short*>(X);
       const bool vec = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (ldx % 8 == 0);
+      const bool aligned = vec && (tokens % HBK == 0) && (C % GBM == 0);
+      if (aligned) {
+        const size_t lds = (size_t)RING * DSTAGE;
+        if (x_dtype == GPTQ_F16) {
+          GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_dma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          hessian16_dma_kernel<false><<<blocks, 256, lds, s>>>(H, ldh, x, ldx, C, tokens, alpha, beta);
+        } else {
+          GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_dma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          hessian16_dma_kernel<true><<<blocks, 256, lds, s>>>(H, ldh, x, ldx, C, tokens, alpha, beta);
+        }
+        break;
+      }
       const size_t lds = sizeof(unsigned short) * 4 * HTILE;
       if (x_dtype == GPTQ_F16) {
         GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
