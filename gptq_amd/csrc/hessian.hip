@@ -225,7 +225,7 @@ constexpr int DSTAGE = 2 * HBK * 256;        // bytes per ring slot: A + B, 64 r
 
 __device__ __forceinline__ void dma_stage(const unsigned short* __restrict__ Xa, const unsigned short* __restrict__ Xb,
                                           long ldx, int k0, char* slot, int wave, int lane) {
-  // wave w moves token rows [16w, 16w+16) of both operands: 4 + 4 one-KiB pieces
+  // loader wave w moves token rows [16w, 16w+16) of both operands: 4 + 4 one-KiB pieces
   const int rl = lane >> 4;                                   // row inside the 4-row piece
   const int chunk = (lane & 15) ^ (rl << 2);                  // logical 16-byte chunk this lane fetches
 #pragma unroll
@@ -260,8 +260,10 @@ __device__ __forceinline__ s16x8 join8(frag_t lo, frag_t hi) {
     TR_READ(F[7], ab1, (KK) * 4096 + 1024);         \
   } while (0)
 
+// Workgroup = 8 waves: waves 0-3 own the MFMA quadrants, waves 4-7 only issue LDS-DMA (an LDS-DMA
+// piece costs its wave ~100-185 cycles of issue; interleaved with the MFMAs it serialised them).
 template <bool BF16>
-__global__ __launch_bounds__(256) void hessian16_dma_kernel(float* __restrict__ H, int ldh,
+__global__ __launch_bounds__(512) void hessian16_dma_kernel(float* __restrict__ H, int ldh,
                                                             const unsigned short* __restrict__ X, int ldx, int C,
                                                             int tokens, float alpha, float beta) {
   extern __shared__ __attribute__((aligned(1024))) char ring[];          // RING x DSTAGE, the ONLY LDS object
@@ -270,9 +272,28 @@ __global__ __launch_bounds__(256) void hessian16_dma_kernel(float* __restrict__ 
   hessian_tile_of(blockIdx.x, nt, ti, tj);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const bool loader = wave >= 4;                              // wave-uniform role
+  const int wm = (wave >> 1) & 1, wn = wave & 1;
   const unsigned short* Xa = X + (long)ti * GBM;
   const unsigned short* Xb = X + (long)tj * GBN;
+  const int nk = tokens / HBK;
+
+  if (loader) {
+    const int lw = wave - 4;
+#pragma unroll
+    for (int st = 0; st < RING - 1; ++st)
+      if (st < nk) dma_stage(Xa, Xb, ldx, st * HBK, ring + st * DSTAGE, lw, lane);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int ahead = min(RING - 2, nk - 1 - kt);           // stages issued after stage kt (uniform)
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                           // stage kt landed; slot (kt-1) % RING is free
+      if (kt + RING - 1 < nk)
+        dma_stage(Xa, Xb, ldx, (kt + RING - 1) * HBK, ring + ((kt + RING - 1) % RING) * DSTAGE, lw, lane);
+    }
+    return;
+  }
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -293,19 +314,8 @@ __global__ __launch_bounds__(256) void hessian16_dma_kernel(float* __restrict__ 
   }
 
   const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)ring);
-  const int nk = tokens / HBK;
-#pragma unroll
-  for (int st = 0; st < RING - 1; ++st)
-    if (st < nk) dma_stage(Xa, Xb, ldx, st * HBK, ring + st * DSTAGE, wave, lane);
-
   for (int kt = 0; kt < nk; ++kt) {
-    const int ahead = min(RING - 2, nk - 1 - kt);             // stages issued after stage kt (uniform)
-    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                             // stage kt landed for all waves; slot (kt-1)%RING is free
-    if (kt + RING - 1 < nk)
-      dma_stage(Xa, Xb, ldx, (kt + RING - 1) * HBK, ring + ((kt + RING - 1) % RING) * DSTAGE, wave, lane);
+    __builtin_amdgcn_s_barrier();                             // pairs with the loaders' barrier of stage kt
     // Fragment reads go through inline asm: hipcc treats every LDS read as aliasing the in-flight
     // LDS-DMA and would drain it with vmcnt(0).  We order them ourselves: the counted vmcnt + barrier
     // above cover the DMA, lgkmcnt(0) + sched_barrier cover the reads (the MFMAs are register-only and
@@ -397,10 +407,10 @@ extern "C" int gptq_hessian_accum(float* H, int ldh, const void* X, int x_dtype,
         const size_t lds = (size_t)RING * DSTAGE;
         if (x_dtype == GPTQ_F16) {
           GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_dma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          hessian16_dma_kernel<false><<<blocks, 256, lds, s>>>(H, ldh, x, ldx, C, tokens, alpha, beta);
+          hessian16_dma_kernel<false><<<blocks, 512, lds, s>>>(H, ldh, x, ldx, C, tokens, alpha, beta);
         } else {
           GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_dma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          hessian16_dma_kernel<true><<<blocks, 256, lds, s>>>(H, ldh, x, ldx, C, tokens, alpha, beta);
+          hessian16_dma_kernel<true><<<blocks, 512, lds, s>>>(H, ldh, x, ldx, C, tokens, alpha, beta);
         }
         break;
       }
