@@ -69,8 +69,8 @@ __device__ __forceinline__ float quad_bcast(float v) {
 
 __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__ A, float* __restrict__ Linv,
                                                              int Cp, int kb, int32_t* __restrict__ info) {
-  constexpr int LD = NB + 1;
-  __shared__ float S[NB * LD];
+  constexpr int LD = NB + 4;     // 16-byte aligned rows: the inverse reads S[i][4jj..4jj+3] as one b128
+  __shared__ __attribute__((aligned(16))) float S[NB * LD];
   __shared__ float rdiag[NB];
   __shared__ float colbuf[2][NB];
   const int tid = threadIdx.x;
@@ -149,6 +149,9 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
 #pragma unroll
   for (int jj = 0; jj < 32; ++jj) {
     if (jj < (c0 >> 2)) continue;    // wave-uniform: rows above every column of the wave are zero
+    float4 s4[32];                   // L[i][4jj .. 4jj+3] for this lane's rows i = 4r + q, r >= jj
+#pragma unroll
+    for (int r = jj; r < 32; ++r) s4[r] = *reinterpret_cast<const float4*>(&S[(4 * r + q) * LD + 4 * jj]);
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
       const int j = 4 * jj + qq;
@@ -159,7 +162,8 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
 #pragma unroll
       for (int r = jj; r < 32; ++r) {
         const int i = 4 * r + q;
-        if (i > j) x[r] -= S[i * LD + j] * xj;
+        const float lij = (qq == 0) ? s4[r].x : (qq == 1) ? s4[r].y : (qq == 2) ? s4[r].z : s4[r].w;
+        if (i > j) x[r] -= lij * xj;
       }
     }
   }
@@ -185,9 +189,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void panel_kernel(float* __restrict__
 }
 
 // Trailing update:  A[m][n] -= sum_k P[m][k] P[n][k]  on the lower tiles of the remaining matrix.
-__global__ __launch_bounds__(GEMM_THREADS) void syrk_kernel(float* __restrict__ A, int Cp, int kb, int nrem) {
+// `first` offsets the linear tile id: id 0 is the next diagonal tile (kb+1, kb+1), which the look-ahead
+// schedule updates on its own so that the next diagonal factorization can start early.
+__global__ __launch_bounds__(GEMM_THREADS) void syrk_kernel(float* __restrict__ A, int Cp, int kb, int nrem,
+                                                            int first) {
   __shared__ __attribute__((aligned(16))) float smem[GEMM_LDS_FLOATS];
-  int rest = blockIdx.x, tn = 0;           // column tile tn, row tile tm >= tn
+  int rest = blockIdx.x + first, tn = 0;   // column tile tn, row tile tm >= tn
   while (rest >= nrem - tn) { rest -= nrem - tn; ++tn; }
   const int tm = tn + rest;
   const long r0 = (long)(kb + 1 + tm) * NB, c0 = (long)(kb + 1 + tn) * NB;
@@ -276,14 +283,31 @@ extern "C" int gptq_hinv_upper(float* H, int ldh, int C, float percdamp, const i
 
   diag_mean_kernel<<<1, 256, 0, s>>>(H, ldh, C, percdamp, damp, info);
   build_abar_kernel<<<dim3(cdiv(Cp, 256), Cp), 256, 0, s>>>(H, ldh, C, Cp, perm, damp, A);
+  // Look-ahead: the diagonal factorization of panel kb+1 only needs tile (kb+1, kb+1), so that tile is
+  // updated on the caller's stream right after panel kb and the rest of the trailing SYRK runs on a
+  // helper stream underneath the (serial, latency-bound) factorization.
+  SideCtx* sc = side_ctx();
+  bool side_busy = false;
   for (int kb = 0; kb < nblk; ++kb) {
     potrf_inv_diag_kernel<<<1, 512, 0, s>>>(A, Linv, Cp, kb, info);
     const int nrem = nblk - kb - 1;
-    if (nrem > 0) {
-      panel_kernel<<<nrem, GEMM_THREADS, 0, s>>>(A, Linv, Cp, kb);
-      syrk_kernel<<<nrem * (nrem + 1) / 2, GEMM_THREADS, 0, s>>>(A, Cp, kb, nrem);
+    if (nrem <= 0) break;
+    if (side_busy) GPTQ_CHECK_HIP(hipStreamWaitEvent(s, sc->side_done, 0));   // SYRK of panel kb-1 finished
+    panel_kernel<<<nrem, GEMM_THREADS, 0, s>>>(A, Linv, Cp, kb);
+    const int ntiles = nrem * (nrem + 1) / 2;
+    if (sc && ntiles > 1) {
+      syrk_kernel<<<1, GEMM_THREADS, 0, s>>>(A, Cp, kb, nrem, 0);
+      GPTQ_CHECK_HIP(hipEventRecord(sc->main_done, s));
+      GPTQ_CHECK_HIP(hipStreamWaitEvent(sc->stream, sc->main_done, 0));
+      syrk_kernel<<<ntiles - 1, GEMM_THREADS, 0, sc->stream>>>(A, Cp, kb, nrem, 1);
+      GPTQ_CHECK_HIP(hipEventRecord(sc->side_done, sc->stream));
+      side_busy = true;
+    } else {
+      syrk_kernel<<<ntiles, GEMM_THREADS, 0, s>>>(A, Cp, kb, nrem, 0);
+      side_busy = false;
     }
   }
+  if (side_busy) GPTQ_CHECK_HIP(hipStreamWaitEvent(s, sc->side_done, 0));
   for (int sz = 1; sz < nblk; sz *= 2) {
     const int pairs = cdiv(nblk, 2 * sz);
     trtri_step1_kernel<<<dim3(sz * sz, pairs), GEMM_THREADS, 0, s>>>(A, Linv, Cp, nblk, sz);

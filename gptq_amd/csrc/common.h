@@ -39,6 +39,15 @@ void set_error(const char* fmt, ...);
     }                                                               \
   } while (0)
 
+// Per-device helper stream + events for look-ahead overlap inside one library call (created once,
+// reused; the caller's stream stays the only externally visible ordering point).
+struct SideCtx {
+  hipStream_t stream = nullptr;
+  hipEvent_t main_done = nullptr;   // recorded on the caller's stream
+  hipEvent_t side_done = nullptr;   // recorded on the side stream
+};
+SideCtx* side_ctx();                // nullptr if it cannot be created (callers then run serially)
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

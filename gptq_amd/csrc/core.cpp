@@ -2,9 +2,29 @@
 #include <stdarg.h>
 #include <stdio.h>
 
-#include "../../include/gptq_hip.h"
+#include <mutex>
+
+#include "common.h"
 
 namespace gptq {
+SideCtx* side_ctx() {
+  static std::mutex mu;
+  static SideCtx ctx[64];
+  static bool ready[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!ready[dev]) {
+    SideCtx c;
+    if (hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&c.main_done, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&c.side_done, hipEventDisableTiming) != hipSuccess) return nullptr;
+    ctx[dev] = c;
+    ready[dev] = true;
+  }
+  return &ctx[dev];
+}
+
 static thread_local char g_err[512] = "";
 
 void set_error(const char* fmt, ...) {

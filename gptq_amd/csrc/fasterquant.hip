@@ -297,6 +297,8 @@ __global__ __launch_bounds__(256) void quant_block_kernel(QuantBlockArgs a) {
 }
 
 // W[:, i2:] -= Err1 @ U[i1:i2, i2:]   (gptq.py:276), exact-fp32 MFMA.
+// [i2, c_end) is the column range this launch updates (the look-ahead schedule splits the update into
+// "next block" and "rest").
 __global__ __launch_bounds__(GEMM_THREADS) void trailing_kernel(float* __restrict__ W, int ldw, int R, int C,
                                                                 int i1, int i2, int B,
                                                                 const float* __restrict__ Err,
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void trailing_kernel(float* __restric
   const int tn = blockIdx.x, tm = blockIdx.y;
   const long r0 = (long)tm * GBM, c0 = (long)i2 + (long)tn * GBN;
   Operand<float> a{Err + r0 * B, B, 1, (int)min((long)GBM, R - r0), true};
-  Operand<float> b{U + (long)i1 * ldu + c0, 1, ldu, (int)min((long)GBN, C - c0), bvec};
+  Operand<float> b{U + (long)i1 * ldu + c0, 1, ldu, (int)min((long)GBN, C - c0), bvec};   // C = end of range
   float* Wt = W + r0 * ldw + c0;
   gemm_tile<float, float, true, false>(a, b, 0, B, smem,
                                        [=](int r, int c, float v) { Wt[(long)r * ldw + c] -= v; });
@@ -388,7 +390,7 @@ SolveWs carve_solve(void* base, int R, int C, int blocksize, int groupsize, int 
   SolveWs w{};
   const int G = groupsize > 0 ? cdiv(C, groupsize) : 1;
   w.Wp = actorder ? cv.take<float>((size_t)R * C) : nullptr;
-  w.Err = cv.take<float>((size_t)R * blocksize);
+  w.Err = cv.take<float>((size_t)2 * R * blocksize);   // double buffered for the look-ahead schedule
   w.loss = cv.take<float>(R);
   w.diag = cv.take<float>(C);
   w.stab = cv.take<float>((size_t)R * G);
@@ -475,29 +477,61 @@ extern "C" int gptq_fasterquant(float* W, int ldw, float* H, int ldh, int R, int
   GPTQ_CHECK_HIP(hipMemsetAsync(ws.loss, 0, sizeof(float) * R, s));
 
   const bool bvec_base = (ldh % 4 == 0) && (reinterpret_cast<uintptr_t>(H) % 16 == 0);
-  for (int i1 = 0; i1 < C; i1 += blocksize) {                    // gptq.py:191
+  // Look-ahead: after block b only the NEXT block's columns are updated on the caller's stream; the
+  // rest of the trailing GEMM runs on a helper stream underneath the column loop of block b+1 (which
+  // is latency-bound and leaves most CUs idle).  Err1 is double buffered for that.
+  SideCtx* sc = side_ctx();
+  bool side_busy = false;
+  int blk = 0;
+  for (int i1 = 0; i1 < C; i1 += blocksize, ++blk) {              // gptq.py:191
     const int i2 = std::min(i1 + blocksize, C);
     const int count = i2 - i1;
+    float* Err = ws.Err + (size_t)(blk & 1) * R * blocksize;
     if (grouped && !use_static) {
       // dynamic groups starting inside this block read the CURRENT global W (gptq.py:253-255)
       const int first = cdiv(i1, groupsize) * groupsize;
       if (first < i2) {
         const int ngb = cdiv(i2 - first, groupsize);
         const int c1 = std::min(C, first + ngb * groupsize);
+        if (c1 > i2 && side_busy) {                              // group reaches past this block
+          GPTQ_CHECK_HIP(hipStreamWaitEvent(s, sc->side_done, 0));
+          side_busy = false;
+        }
         find_params_kernel<<<dim3(cdiv(R, 4), ngb), 256, 0, s>>>(Wk, ldk, R, first, c1, groupsize, maxq, sym,
                                                                  ws.stab, ws.ztab, G, first / groupsize);
       }
     }
     QuantBlockArgs a{Wk, ldk, R, i1, count, H, ldh, ws.stab, ws.ztab, G,
-                     grouped ? ws.cgroup : nullptr, maxq, ws.Err, codes, C, perm, ws.loss};
+                     grouped ? ws.cgroup : nullptr, maxq, Err, codes, C, perm, ws.loss};
     const int rc = launch_quant_block(a, blocksize, grouped, s);
     if (rc != GPTQ_OK) return rc;
+    if (side_busy) {                                             // rest-update of block b-1 must land first
+      GPTQ_CHECK_HIP(hipStreamWaitEvent(s, sc->side_done, 0));
+      side_busy = false;
+    }
     if (i2 < C) {
       const bool bvec = bvec_base && (i2 % 4 == 0);
-      trailing_kernel<<<dim3(cdiv(C - i2, GBN), cdiv(R, GBM)), GEMM_THREADS, 0, s>>>(
-          Wk, ldk, R, C, i1, i2, blocksize, ws.Err, H, ldh, bvec);
+      const int next_end = std::min(C, i2 + blocksize);
+      trailing_kernel<<<dim3(cdiv(next_end - i2, GBN), cdiv(R, GBM)), GEMM_THREADS, 0, s>>>(
+          Wk, ldk, R, next_end, i1, i2, blocksize, Err, H, ldh, bvec);
+      if (next_end < C) {
+        const bool bvec2 = bvec_base && (next_end % 4 == 0);
+        hipStream_t ts = s;
+        if (sc) {
+          GPTQ_CHECK_HIP(hipEventRecord(sc->main_done, s));
+          GPTQ_CHECK_HIP(hipStreamWaitEvent(sc->stream, sc->main_done, 0));
+          ts = sc->stream;
+        }
+        trailing_kernel<<<dim3(cdiv(C - next_end, GBN), cdiv(R, GBM)), GEMM_THREADS, 0, ts>>>(
+            Wk, ldk, R, C, i1, next_end, blocksize, Err, H, ldh, bvec2);
+        if (sc) {
+          GPTQ_CHECK_HIP(hipEventRecord(sc->side_done, sc->stream));
+          side_busy = true;
+        }
+      }
     }
   }
+  if (side_busy) GPTQ_CHECK_HIP(hipStreamWaitEvent(s, sc->side_done, 0));
   if (actorder)                                                  // gptq.py:300-301
     permute_cols_kernel<float, true><<<dim3(cdiv(C, TB), R), TB, 0, s>>>(ws.Wp, C, W, ldw, C, ws.perm);
 
