@@ -69,8 +69,8 @@ __device__ __forceinline__ float quad_bcast(float v) {
 
 __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__ A, float* __restrict__ Linv,
                                                              int Cp, int kb, int32_t* __restrict__ info) {
-  constexpr int LD = NB + 4;     // 16-byte aligned rows: the inverse reads S[i][4jj..4jj+3] as one b128
-  __shared__ __attribute__((aligned(16))) float S[NB * LD];
+  constexpr int LD = NB + 1;
+  __shared__ float S[NB * LD];
   __shared__ float rdiag[NB];
   __shared__ float colbuf[2][NB];
   const int tid = threadIdx.x;
@@ -149,9 +149,6 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
 #pragma unroll
   for (int jj = 0; jj < 32; ++jj) {
     if (jj < (c0 >> 2)) continue;    // wave-uniform: rows above every column of the wave are zero
-    float4 s4[32];                   // L[i][4jj .. 4jj+3] for this lane's rows i = 4r + q, r >= jj
-#pragma unroll
-    for (int r = jj; r < 32; ++r) s4[r] = *reinterpret_cast<const float4*>(&S[(4 * r + q) * LD + 4 * jj]);
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
       const int j = 4 * jj + qq;
@@ -162,8 +159,7 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
 #pragma unroll
       for (int r = jj; r < 32; ++r) {
         const int i = 4 * r + q;
-        const float lij = (qq == 0) ? s4[r].x : (qq == 1) ? s4[r].y : (qq == 2) ? s4[r].z : s4[r].w;
-        if (i > j) x[r] -= lij * xj;
+        if (i > j) x[r] -= S[i * LD + j] * xj;
       }
     }
   }
@@ -286,7 +282,7 @@ extern "C" int gptq_hinv_upper(float* H, int ldh, int C, float percdamp, const i
   // Look-ahead: the diagonal factorization of panel kb+1 only needs tile (kb+1, kb+1), so that tile is
   // updated on the caller's stream right after panel kb and the rest of the trailing SYRK runs on a
   // helper stream underneath the (serial, latency-bound) factorization.
-  SideCtx* sc = side_ctx();
+  SideCtx* sc = (lookahead_mask() & 1) ? side_ctx() : nullptr;
   bool side_busy = false;
   for (int kb = 0; kb < nblk; ++kb) {
     potrf_inv_diag_kernel<<<1, 512, 0, s>>>(A, Linv, Cp, kb, info);

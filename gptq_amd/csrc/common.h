@@ -47,6 +47,7 @@ struct SideCtx {
   hipEvent_t side_done = nullptr;   // recorded on the side stream
 };
 SideCtx* side_ctx();                // nullptr if it cannot be created (callers then run serially)
+int lookahead_mask();               // bit 0: factorization chain, bit 1: column loop (env GPTQ_LOOKAHEAD)
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -1,6 +1,7 @@
 // Error reporting and ABI version of libgptq_hip.so.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <mutex>
 
@@ -23,6 +24,14 @@ SideCtx* side_ctx() {
     ready[dev] = true;
   }
   return &ctx[dev];
+}
+
+int lookahead_mask() {
+  static int mask = [] {
+    const char* e = getenv("GPTQ_LOOKAHEAD");
+    return e ? atoi(e) : 2;
+  }();
+  return mask;
 }
 
 static thread_local char g_err[512] = "";
