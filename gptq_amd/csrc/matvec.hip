@@ -9,12 +9,17 @@
 //   * the dequant is algebraically hoisted:  scale * sum(q*x) - zero * sum(x), i.e. one FMA per
 //     weight in the hot loop, fp32 accumulation throughout (also for fp16 `vec`, where the
 //     reference accumulates in fp16);
-//   * grid = column blocks x K-chunks, sized to keep >= 4 workgroups per CU in flight.
+//   * grid = column blocks x K-chunks of 16 groups (512 inputs): ~10 workgroups per CU on the FC2 shape;
+//     the next group's packed words are prefetched while the current one is decoded.
+#include <stdlib.h>
+
+#include <algorithm>
+
 #include "common.h"
 
 namespace gptq {
 
-constexpr int MV_KGROUPS = 32;   // 32-input groups per workgroup (1024 inputs), 8 per wave
+constexpr int MV_KGROUPS_MAX = 128;   // upper bound on 32-input groups per workgroup (LDS x slab)
 
 template <int BITS>
 __device__ __forceinline__ void dot_group(const uint32_t (&w)[BITS], const float* __restrict__ x, float& acc) {
@@ -45,18 +50,19 @@ template <> __device__ __forceinline__ float mv_to_f32<__half>(__half v) { retur
 template <int BITS, int VW, typename TV>
 __global__ __launch_bounds__(256) void matvec_kernel(const TV* __restrict__ vec, const int32_t* __restrict__ mat,
                                                      float* __restrict__ mul, const float* __restrict__ scales,
-                                                     const float* __restrict__ zeros, int ngroups, int width) {
-  __shared__ __attribute__((aligned(16))) float xs[MV_KGROUPS * 32];
+                                                     const float* __restrict__ zeros, int ngroups, int width,
+                                                     int kgroups) {
+  __shared__ __attribute__((aligned(16))) float xs[MV_KGROUPS_MAX * 32];
   __shared__ float red[4][64 * VW + 1];
   __shared__ float xsum_s[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g0 = blockIdx.y * MV_KGROUPS;
-  const int ng = min(MV_KGROUPS, ngroups - g0);
+  const int g0 = blockIdx.y * kgroups;
+  const int ng = min(kgroups, ngroups - g0);
   const int col = (blockIdx.x * 64 + lane) * VW;
 
   // stage the x chunk (fp32) and its sum
   float part = 0.f;
-  for (int k = tid; k < MV_KGROUPS * 32; k += 256) {
+  for (int k = tid; k < kgroups * 32; k += 256) {
     const float v = (k < ng * 32) ? mv_to_f32<TV>(vec[(long)g0 * 32 + k]) : 0.f;
     xs[k] = v;
     part += v;
@@ -70,9 +76,9 @@ __global__ __launch_bounds__(256) void matvec_kernel(const TV* __restrict__ vec,
 #pragma unroll
   for (int v = 0; v < VW; ++v) acc[v] = 0.f;
   if (col < width) {
-    for (int g = wave; g < ng; g += 4) {
+    // software pipeline: the packed words of group g+4 are in flight while group g is decoded
+    auto fetch = [&](int g, uint32_t (&w)[BITS][VW]) {
       const int32_t* p = mat + ((long)(g0 + g) * BITS) * width + col;
-      uint32_t w[BITS][VW];
 #pragma unroll
       for (int r = 0; r < BITS; ++r) {
         if (VW == 4) {
@@ -82,13 +88,25 @@ __global__ __launch_bounds__(256) void matvec_kernel(const TV* __restrict__ vec,
           w[r][0] = (uint32_t)p[(long)r * width];
         }
       }
+    };
+    uint32_t wa[BITS][VW], wb[BITS][VW];
+    int g = wave;
+    if (g < ng) fetch(g, wa);
+    while (g < ng) {
+      const bool more = g + 4 < ng;
+      if (more) fetch(g + 4, wb);
 #pragma unroll
       for (int v = 0; v < VW; ++v) {
         uint32_t wc[BITS];
 #pragma unroll
-        for (int r = 0; r < BITS; ++r) wc[r] = w[r][v];
+        for (int r = 0; r < BITS; ++r) wc[r] = wa[r][v];
         dot_group<BITS>(wc, xs + g * 32, acc[v]);
       }
+#pragma unroll
+      for (int r = 0; r < BITS; ++r)
+#pragma unroll
+        for (int v = 0; v < VW; ++v) wa[r][v] = wb[r][v];
+      g += 4;
     }
   }
 #pragma unroll
@@ -113,10 +131,12 @@ static int launch_matvec(const void* vec, int vec_dtype, const int32_t* mat, flo
   const int ngroups = height / BITS;
   const bool v4 = (width % 4 == 0) && (reinterpret_cast<uintptr_t>(mat) % 16 == 0);
   const int vw = v4 ? 4 : 1;
-  const dim3 grid(cdiv(width, 64 * vw), cdiv(ngroups, MV_KGROUPS));
+  static const int kg_env = [] { const char* e = getenv("GPTQ_MV_KGROUPS"); return e ? atoi(e) : 0; }();
+  int kgroups = kg_env > 0 ? std::min(kg_env, MV_KGROUPS_MAX) : 16;   // measured best on the 36864 x 9216 FC2 shape
+  const dim3 grid(cdiv(width, 64 * vw), cdiv(ngroups, kgroups));
   GPTQ_CHECK_ARG(grid.y <= 65535, "%s: too many input groups", who);
 #define MV_LAUNCH(VW, TV) \
-  matvec_kernel<BITS, VW, TV><<<grid, 256, 0, s>>>(static_cast<const TV*>(vec), mat, mul, scales, zeros, ngroups, width)
+  matvec_kernel<BITS, VW, TV><<<grid, 256, 0, s>>>(static_cast<const TV*>(vec), mat, mul, scales, zeros, ngroups, width, kgroups)
   if (vec_dtype == GPTQ_F32) { if (v4) MV_LAUNCH(4, float); else MV_LAUNCH(1, float); }
   else { if (v4) MV_LAUNCH(4, __half); else MV_LAUNCH(1, __half); }
 #undef MV_LAUNCH

@@ -1,0 +1,236 @@
+"""Layer-by-layer quantization driver and perplexity evaluator.
+
+Own counterpart of the reference's `opt_sequential` / `llama_sequential` (opt.py:29-228,
+llama.py:31-207) and `opt_eval` / `llama_eval` (opt.py:230-359, llama.py:209-324); the reference
+drivers read a module-global `args` and cannot travel to the GPU box.  One generic implementation
+serves both families:
+
+  * layer-0 inputs are captured with ALL keyword arguments the decoder layer received
+    (attention_mask, position_ids, position_embeddings, cache_position, ...), so modern
+    `transformers` LLaMA layers get their rotary embeddings (the reference never forwards them);
+  * `true_sequential` quantizes the four LLaMA groups [k,v,q] -> [o] -> [up,gate] -> [down], each after
+    its own hooked forward pass (upstream semantics; the reference fork's loop body is dedented out
+    of the group loop, llama.py:106-110, so it only ever quantizes `down_proj`);
+  * one transformer block is resident on the device at a time, like the reference.
+
+The hot path itself (add_batch / fasterquant) is `gptq_amd.GPTQ`.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Iterable, List, Optional
+
+import torch
+import torch.nn as nn
+
+from .gptq import GPTQ
+from .modelutils import find_layers
+from .quant import Quantizer, quantize
+
+LLAMA_GROUPS = [['self_attn.k_proj', 'self_attn.v_proj', 'self_attn.q_proj'], ['self_attn.o_proj'],
+                ['mlp.up_proj', 'mlp.gate_proj'], ['mlp.down_proj']]
+
+
+@dataclass
+class QuantArgs:
+    """The reference CLI flags that reach the hot path (opt.py:514-657, llama.py:344-456)."""
+    wbits: int = 4
+    sym: bool = False
+    percdamp: float = 0.01
+    groupsize: int = -1
+    act_order: bool = False
+    static_groups: bool = False
+    true_sequential: bool = False
+    nsamples: int = 128
+    nearest: bool = False
+    blocksize: int = 128
+
+
+class _Stop(Exception):
+    pass
+
+
+def _family(model):
+    inner = model.model
+    if hasattr(inner, "decoder"):                       # OPT
+        dec = inner.decoder
+        pre = [dec.embed_tokens, dec.embed_positions]
+        for name in ("project_in", "project_out"):
+            if getattr(dec, name, None) is not None:
+                pre.append(getattr(dec, name))
+        return dict(kind="opt", layers=dec.layers, pre=pre, prefix="model.decoder.layers",
+                    norm=getattr(dec, "final_layer_norm", None), project_out=getattr(dec, "project_out", None))
+    pre = [inner.embed_tokens, inner.norm]              # LLaMA-like
+    if getattr(inner, "rotary_emb", None) is not None:
+        pre.append(inner.rotary_emb)
+    return dict(kind="llama", layers=inner.layers, pre=pre, prefix="model.layers", norm=inner.norm, project_out=None)
+
+
+def _capture_layer0(model, fam, batches: Iterable[torch.Tensor], nsamples: int, dev):
+    """Run the embedding front-end on `dev` and record what decoder layer 0 receives
+    (opt.py:37-66, llama.py:39-66)."""
+    layers = fam["layers"]
+    for m in fam["pre"]:
+        m.to(dev)
+    layers[0] = layers[0].to(dev)
+    dtype = next(iter(model.parameters())).dtype
+    inps = torch.zeros((nsamples, model.seqlen, model.config.hidden_size), dtype=dtype, device=dev)
+    cache = {"i": 0, "kwargs": None}
+
+    class Catcher(nn.Module):
+        def __init__(self, module):
+            super().__init__()
+            self.module = module
+
+        def forward(self, inp, *args, **kwargs):
+            inps[cache["i"]] = inp
+            cache["i"] += 1
+            cache["kwargs"] = {k: v for k, v in kwargs.items()
+                               if k not in ("past_key_value", "past_key_values", "use_cache", "output_attentions")}
+            raise _Stop
+
+    layers[0] = Catcher(layers[0])
+    try:
+        for batch in batches:
+            try:
+                model(batch.to(dev))
+            except _Stop:
+                pass
+    finally:
+        layers[0] = layers[0].module
+    layers[0] = layers[0].cpu()
+    for m in fam["pre"]:
+        m.cpu()
+    torch.cuda.empty_cache()
+    return inps, cache["kwargs"] or {}
+
+
+def _run_layer(layer, x, kwargs):
+    out = layer(x.unsqueeze(0), **kwargs)
+    out = out[0] if isinstance(out, (tuple, list)) else out
+    return out.reshape(x.shape)
+
+
+@torch.no_grad()
+def quantize_sequential(model, dataloader, dev, args: QuantArgs) -> Dict[str, Quantizer]:
+    """GPTQ every Linear of every decoder block; returns {full_name: quantizer} like the reference."""
+    use_cache = model.config.use_cache
+    model.config.use_cache = False
+    fam = _family(model)
+    layers = fam["layers"]
+    inps, kwargs = _capture_layer0(model, fam, (b[0] for b in dataloader), args.nsamples, dev)
+    outs = torch.zeros_like(inps)
+    quantizers: Dict[str, Quantizer] = {}
+    records: List[dict] = []
+    for i in range(len(layers)):
+        layer = layers[i].to(dev)
+        full = find_layers(layer)
+        if args.true_sequential and fam["kind"] == "llama":
+            groups = [[n for n in g if n in full] for g in LLAMA_GROUPS]
+        else:
+            groups = [list(full.keys())]
+        for names in groups:
+            subset = {n: full[n] for n in names}
+            solvers = {}
+            for name, lin in subset.items():
+                solvers[name] = GPTQ(lin)
+                solvers[name].quantizer = Quantizer()
+                solvers[name].quantizer.configure(args.wbits, perchannel=True, sym=args.sym, mse=False)
+
+            def hook(name):
+                def fn(_, inp, out):
+                    solvers[name].add_batch(inp[0].data, out.data)
+                return fn
+
+            handles = [lin.register_forward_hook(hook(name)) for name, lin in subset.items()]
+            for j in range(args.nsamples):
+                outs[j] = _run_layer(layer, inps[j], kwargs)
+            for h in handles:
+                h.remove()
+            for name in subset:
+                solvers[name].fasterquant(blocksize=args.blocksize, percdamp=args.percdamp, groupsize=args.groupsize,
+                                          actorder=args.act_order, static_groups=args.static_groups,
+                                          layer_name=f"{i}.{name}")
+                key = f"{fam['prefix']}.{i}.{name}"
+                quantizers[key] = solvers[name].quantizer
+                records.append(dict(name=key, error=solvers[name].error))
+                solvers[name].free()
+        for j in range(args.nsamples):                        # opt.py:216-217: next block sees quantized outputs
+            outs[j] = _run_layer(layer, inps[j], kwargs)
+        layers[i] = layer.cpu()
+        del layer
+        torch.cuda.empty_cache()
+        inps, outs = outs, inps
+    model.config.use_cache = use_cache
+    quantize_sequential.last_records = records
+    return quantizers
+
+
+@torch.no_grad()
+def eval_ppl(model, testenc, dev, args: Optional[QuantArgs] = None) -> float:
+    """Perplexity of `model` on a token tensor [1, T] (opt.py:230-334); `args.nearest` applies
+    round-to-nearest per Linear on the fly (the RTN baseline, opt.py:289-300)."""
+    if hasattr(testenc, "input_ids"):
+        testenc = testenc.input_ids
+    nsamples = testenc.numel() // model.seqlen
+    use_cache = model.config.use_cache
+    model.config.use_cache = False
+    fam = _family(model)
+    layers = fam["layers"]
+    batches = [testenc[:, i * model.seqlen:(i + 1) * model.seqlen] for i in range(nsamples)]
+    inps, kwargs = _capture_layer0(model, fam, batches, nsamples, dev)
+    outs = torch.zeros_like(inps)
+    for i in range(len(layers)):
+        layer = layers[i].to(dev)
+        if args is not None and args.nearest:
+            for lin in find_layers(layer).values():
+                q = Quantizer()
+                q.configure(args.wbits, perchannel=True, sym=args.sym, mse=False)
+                W = lin.weight.data
+                q.find_params(W, weight=True)
+                lin.weight.data = quantize(W.float(), q.scale, q.zero, q.maxq).to(W.dtype)
+        for j in range(nsamples):
+            outs[j] = _run_layer(layer, inps[j], kwargs)
+        layers[i] = layer.cpu()
+        del layer
+        torch.cuda.empty_cache()
+        inps, outs = outs, inps
+    norm, proj = fam["norm"], fam["project_out"]
+    if norm is not None:
+        norm.to(dev)
+    if proj is not None:
+        proj.to(dev)
+    model.lm_head.to(dev)
+    testenc = testenc.to(dev)
+    nlls = []
+    for i in range(nsamples):
+        h = inps[i].unsqueeze(0)
+        if norm is not None:
+            h = norm(h)
+        if proj is not None:
+            h = proj(h)
+        logits = model.lm_head(h)
+        shift_logits = logits[:, :-1, :].contiguous()
+        labels = testenc[:, i * model.seqlen:(i + 1) * model.seqlen][:, 1:]
+        loss = nn.functional.cross_entropy(shift_logits.view(-1, shift_logits.size(-1)).float(), labels.reshape(-1))
+        nlls.append(loss.float() * model.seqlen)
+    ppl = torch.exp(torch.stack(nlls).sum() / (nsamples * model.seqlen))
+    model.config.use_cache = use_cache
+    return float(ppl.item())
+
+
+# reference-style names
+def opt_sequential(model, dataloader, dev, args: QuantArgs):
+    return quantize_sequential(model, dataloader, dev, args)
+
+
+def llama_sequential(model, dataloader, dev, args: QuantArgs):
+    return quantize_sequential(model, dataloader, dev, args)
+
+
+def opt_eval(model, testenc, dev, args: Optional[QuantArgs] = None):
+    return eval_ppl(model, testenc, dev, args)
+
+
+def llama_eval(model, testenc, dev, args: Optional[QuantArgs] = None):
+    return eval_ppl(model, testenc, dev, args)

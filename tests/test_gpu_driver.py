@@ -1,0 +1,133 @@
+"""Driver-level parity: our sequential driver + evaluator on the GPU against
+the reference's opt_sequential / opt_eval run on CPU in the build container (oracle/gen_golden_driver.py)."""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def tiny_opt(init=None):
+    from transformers import OPTConfig, OPTForCausalLM
+    cfg = OPTConfig(vocab_size=128, hidden_size=64, ffn_dim=256, num_hidden_layers=2, num_attention_heads=4,
+                    max_position_embeddings=128, word_embed_proj_dim=64, do_layer_norm_before=True,
+                    dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, layerdrop=0.0)
+    torch.manual_seed(0)
+    m = OPTForCausalLM(cfg).float().eval()
+    if init is not None:
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in init.items()}, strict=False)
+    m.seqlen = 128
+    return m
+
+
+def test_tiny_opt_matches_reference_driver(hip_device):
+    import gptq_amd.gptq as gmod
+    from gptq_amd.sequential import QuantArgs, eval_ppl, opt_sequential
+    gmod.VERBOSE = False
+    g = load_golden("g6_opt_tiny")
+    init = {k[5:]: v for k, v in g.items() if k.startswith("init/")}
+    calib = torch.from_numpy(g["calib"])
+    test = torch.from_numpy(g["test"])
+
+    ppl_fp = eval_ppl(tiny_opt(init), test, hip_device)
+    assert abs(ppl_fp - float(g["ppl_fp"])) <= 2e-3 * float(g["ppl_fp"])
+    args = QuantArgs(wbits=4, nsamples=4, groupsize=-1, static_groups=True)
+    ppl_rtn = eval_ppl(tiny_opt(init), test, hip_device, QuantArgs(wbits=4, nearest=True))
+    assert abs(ppl_rtn - float(g["ppl_rtn4"])) <= 2e-3 * float(g["ppl_rtn4"])
+
+    model = tiny_opt(init)
+    quantizers = opt_sequential(model, [(calib[i], None) for i in range(4)], hip_device, args)
+    recs = opt_sequential.__globals__["quantize_sequential"].last_records
+    names = [r["name"].split("layers.")[1] for r in recs]
+    assert names == list(g["names_in_order"]) or len(names) == len(g["errors"])
+    errs = np.array([r["error"] for r in recs])
+    # layer 0 sees identical inputs (up to GPU-vs-CPU matmul rounding); layer 1 sees quantized layer-0
+    # outputs, where an occasional flipped code upstream moves the Hessian slightly
+    assert np.allclose(errs[:6], g["errors"][:6], rtol=2e-3), (errs[:6], g["errors"][:6])
+    assert np.allclose(errs[6:], g["errors"][6:], rtol=5e-2), (errs[6:], g["errors"][6:])
+    sd = model.state_dict()
+    worst = 0.0
+    for n in sorted(quantizers):
+        ref = torch.from_numpy(g["q/" + n])
+        got = sd[n + ".weight"].float().cpu()
+        rel = float((got - ref).norm() / ref.norm())
+        worst = max(worst, rel)
+        if ".layers.0." in n:
+            assert rel <= 5e-3, (n, rel)
+            assert torch.equal(quantizers[n].scale.cpu(), torch.from_numpy(g["scale/" + n]))
+        assert len(torch.unique(got[0])) <= 16
+    assert worst <= 5e-2
+    ppl_q = eval_ppl(model, test, hip_device)
+    assert abs(ppl_q - float(g["ppl_gptq4"])) <= 0.05
+    print(f"tiny OPT: ppl fp {ppl_fp:.4f} rtn4 {ppl_rtn:.4f} gptq4 {ppl_q:.4f} (ref {float(g['ppl_gptq4']):.4f}); worst Q rel {worst:.2e}")
+
+
+def test_tiny_llama_true_sequential_act_order(hip_device):
+    """BASELINE configs[2] flags on a small random-init LLaMA: every Linear must come back on a 4-bit grid
+    (the reference fork's dedent bug would leave q/k/v/o/up/gate untouched, llama.py:106-110)."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    import gptq_amd.gptq as gmod
+    from gptq_amd.sequential import QuantArgs, eval_ppl, llama_sequential
+    gmod.VERBOSE = False
+    cfg = LlamaConfig(vocab_size=256, hidden_size=128, intermediate_size=352, num_hidden_layers=2,
+                      num_attention_heads=4, num_key_value_heads=4, max_position_embeddings=256)
+    torch.manual_seed(0)
+    model = LlamaForCausalLM(cfg).half().eval()
+    model.seqlen = 256
+    gen = torch.Generator().manual_seed(3)
+    calib = [(torch.randint(0, 256, (1, 256), generator=gen), None) for _ in range(8)]
+    test = torch.randint(0, 256, (1, 256 * 4), generator=gen)
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    ppl_fp = eval_ppl(model, test, hip_device)
+    args = QuantArgs(wbits=4, nsamples=8, act_order=True, true_sequential=True)
+    quantizers = llama_sequential(model, calib, hip_device, args)
+    assert len(quantizers) == 2 * 7
+    sd = model.state_dict()
+    for n in quantizers:
+        w = sd[n + ".weight"]
+        assert not torch.equal(w, before[n + ".weight"]), f"{n} was not quantized"
+        assert len(torch.unique(w[0].float())) <= 16
+    ppl_q = eval_ppl(model, test, hip_device)
+    assert np.isfinite(ppl_q) and abs(ppl_q - ppl_fp) / ppl_fp < 0.05
+    print(f"tiny LLaMA: ppl fp16 {ppl_fp:.3f} -> gptq4 act-order true-sequential {ppl_q:.3f}")
+
+
+def test_opt125m_config1_end_to_end(hip_device):
+    """BASELINE configs[0]: OPT-125m architecture (random init), 4-bit, nsamples = 32 synthetic samples."""
+    from transformers import OPTConfig, OPTForCausalLM
+    import gptq_amd.gptq as gmod
+    from gptq_amd.sequential import QuantArgs, eval_ppl, opt_sequential
+    gmod.VERBOSE = False
+    cfg = OPTConfig(vocab_size=50272, hidden_size=768, ffn_dim=3072, num_hidden_layers=12, num_attention_heads=12,
+                    max_position_embeddings=2048, word_embed_proj_dim=768, do_layer_norm_before=True)
+    torch.manual_seed(0)
+    model = OPTForCausalLM(cfg).half().eval()
+    model.seqlen = 2048
+    gen = torch.Generator().manual_seed(0)
+    calib = [(torch.randint(0, 50272, (1, 2048), generator=gen), None) for _ in range(32)]
+    test = torch.randint(0, 50272, (1, 2048 * 4), generator=gen)
+    ppl_fp = eval_ppl(model, test, hip_device)
+    t0 = time.time()
+    quantizers = opt_sequential(model, calib, hip_device, QuantArgs(wbits=4, nsamples=32, static_groups=True))
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    nparams = sum(model.state_dict()[n + ".weight"].numel() for n in quantizers)
+    assert len(quantizers) == 12 * 6
+    ppl_q = eval_ppl(model, test, hip_device)
+    ppl_rtn = eval_ppl(OPTForCausalLM(cfg).half().eval().__class__.from_pretrained if False else _clone_fp(cfg), test,
+                       hip_device, QuantArgs(wbits=4, nearest=True))
+    print(f"OPT-125m (random init): full quantization {dt:.1f} s = {nparams / dt / 1e6:.1f} Mparams/s end to end; "
+          f"ppl fp16 {ppl_fp:.2f}, rtn4 {ppl_rtn:.2f}, gptq4 {ppl_q:.2f}")
+    assert np.isfinite(ppl_q) and abs(ppl_q - ppl_fp) / ppl_fp < 0.02
+
+
+def _clone_fp(cfg):
+    from transformers import OPTForCausalLM
+    torch.manual_seed(0)
+    m = OPTForCausalLM(cfg).half().eval()
+    m.seqlen = 2048
+    return m
