@@ -180,8 +180,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void panel_kernel(float* __restrict__
   const float* D = Linv + (long)kb * NB * Cp + (long)kb * NB;
   Operand<float> a{P, Cp, 1, NB, true};
   Operand<float> b{D, Cp, 1, NB, true};
-  gemm_tile<float, float, true, true>(a, b, 0, NB, smem,
-                                      [=](int r, int c, float v) { P[(long)r * Cp + c] = v; });
+  gemm_tile<float, float, true, true>(a, b, 0, NB, smem, Epilogue{P, Cp, 1, EPI_STORE, TRI_ALL, 0.f, 0.f});
 }
 
 // Trailing update:  A[m][n] -= sum_k P[m][k] P[n][k]  on the lower tiles of the remaining matrix.
@@ -198,10 +197,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void syrk_kernel(float* __restrict__ 
   Operand<float> b{A + c0 * Cp + (long)kb * NB, Cp, 1, NB, true};
   float* Ct = A + r0 * Cp + c0;
   const bool diag = tm == tn;
-  gemm_tile<float, float, true, true>(a, b, 0, NB, smem, [=](int r, int c, float v) {
-    if (diag && c > r) return;
-    Ct[(long)r * Cp + c] -= v;
-  });
+  gemm_tile<float, float, true, true>(a, b, 0, NB, smem,
+                                      Epilogue{Ct, Cp, 1, EPI_SUB, diag ? TRI_LOWER : TRI_ALL, 0.f, 0.f});
 }
 
 // Recursive-doubling inverse, level with segment size s (in 128-blocks).  For every pair
@@ -221,7 +218,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void trtri_step1_kernel(const float* 
   Operand<float> b{Linv + ka * Cp + cn, 1, Cp, NB, true};         // Ainv[k][n], lower: k >= n
   float* Tt = Linv + cn * Cp + rm;                                // T^T lives at [n][m]
   gemm_tile<float, float, true, false>(a, b, tj * NB, s * NB, smem,
-                                       [=](int r, int c, float v) { Tt[(long)c * Cp + r] = v; });
+                                       Epilogue{Tt, 1, Cp, EPI_STORE, TRI_ALL, 0.f, 0.f});   // transposed store
 }
 
 __global__ __launch_bounds__(GEMM_THREADS) void trtri_step2_kernel(float* __restrict__ Linv, int Cp,
@@ -235,7 +232,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void trtri_step2_kernel(float* __rest
   Operand<float> b{Linv + cn * Cp + kc, Cp, 1, NB, true};         // T[k][n] read from T^T[n][k]
   float* X = Linv + rm * Cp + cn;
   gemm_tile<float, float, true, true>(a, b, 0, (ti + 1) * NB, smem,
-                                      [=](int r, int c, float v) { X[(long)r * Cp + c] = -v; });
+                                      Epilogue{X, Cp, 1, EPI_STORE_NEG, TRI_ALL, 0.f, 0.f});
 }
 
 // U[i][j] = Linv[C-1-i][C-1-j] for j >= i, zero below the diagonal.

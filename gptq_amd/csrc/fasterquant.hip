@@ -310,8 +310,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void trailing_kernel(float* __restric
   Operand<float> a{Err + r0 * B, B, 1, (int)min((long)GBM, R - r0), true};
   Operand<float> b{U + (long)i1 * ldu + c0, 1, ldu, (int)min((long)GBN, C - c0), bvec};   // C = end of range
   float* Wt = W + r0 * ldw + c0;
-  gemm_tile<float, float, true, false>(a, b, 0, B, smem,
-                                       [=](int r, int c, float v) { Wt[(long)r * ldw + c] -= v; });
+  gemm_tile<float, float, true, false>(a, b, 0, B, smem, Epilogue{Wt, ldw, 1, EPI_SUB, TRI_ALL, 0.f, 0.f});
 }
 
 }  // namespace gptq

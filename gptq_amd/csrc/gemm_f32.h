@@ -121,11 +121,65 @@ __device__ __forceinline__ void stage_store(float* S, const float r[2][4]) {
   }
 }
 
-// C_tile = sum_{k in [k_begin, k_end)} A(m,k) * B(n,k); epi(row, col, value) is called for every
-// valid element (row < a.rem, col < b.rem).  `smem` must hold GEMM_LDS_FLOATS floats.
-template <typename TA, typename TB, bool AKC, bool BKC, typename Epi>
+// Epilogue of a tile: how the 128x128 result meets memory.  Element (row, col) lives at
+// C[row * rs + col * cs].  Read-modify-write modes FIRST issue all 64 loads of a lane, then combine,
+// then store: written naively (`C[..] -= v` per element) the compiler must keep each load behind the
+// previous store and every lane pays 64 serialized memory round trips (measured: ~300 us of a 350 us
+// Hessian launch was this).
+enum EpiMode { EPI_STORE = 0, EPI_STORE_NEG = 1, EPI_SUB = 2, EPI_AXPBY = 3 };
+enum EpiTri { TRI_ALL = 0, TRI_LOWER = 1, TRI_UPPER = 2 };   // keep row >= col / row <= col only
+
+struct Epilogue {
+  float* C;
+  long rs, cs;
+  int mode;
+  int tri;
+  float alpha, beta;   // EPI_AXPBY: C = alpha * C + beta * acc
+};
+
+__device__ __forceinline__ void tile_epilogue(const f32x16 (&acc)[2][2], const Epilogue& ep, int rem_m,
+                                              int rem_n, int wm, int wn, int lane) {
+  // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+  const bool rmw = ep.mode == EPI_SUB || ep.mode == EPI_AXPBY;
+  float old[2][2][16];
+  if (rmw) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+          const int col = wn * 64 + j * 32 + (lane & 31);
+          old[i][j][e] = (row < rem_m && col < rem_n) ? ep.C[(long)row * ep.rs + (long)col * ep.cs] : 0.f;
+        }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        const int col = wn * 64 + j * 32 + (lane & 31);
+        bool keep = row < rem_m && col < rem_n;
+        if (ep.tri == TRI_LOWER) keep = keep && row >= col;
+        if (ep.tri == TRI_UPPER) keep = keep && row <= col;
+        const float v = acc[i][j][e];
+        float out;
+        if (ep.mode == EPI_STORE) out = v;
+        else if (ep.mode == EPI_STORE_NEG) out = -v;
+        else if (ep.mode == EPI_SUB) out = old[i][j][e] - v;
+        else out = ep.alpha * old[i][j][e] + ep.beta * v;       // contraction off: fl(fl(a*h) + fl(b*v))
+        if (keep) ep.C[(long)row * ep.rs + (long)col * ep.cs] = out;
+      }
+}
+
+// C_tile = sum_{k in [k_begin, k_end)} A(m,k) * B(n,k), combined with memory as `ep` says.
+// `smem` must hold GEMM_LDS_FLOATS floats.
+template <typename TA, typename TB, bool AKC, bool BKC>
 __device__ __forceinline__ void gemm_tile(const Operand<TA>& a, const Operand<TB>& b, int k_begin,
-                                          int k_end, float* smem, Epi epi) {
+                                          int k_end, float* smem, const Epilogue& ep) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -176,18 +230,7 @@ __device__ __forceinline__ void gemm_tile(const Operand<TA>& a, const Operand<TB
     __syncthreads();
     cur ^= 1;
   }
-
-  // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        const int col = wn * 64 + j * 32 + (lane & 31);
-        if (row < a.rem && col < b.rem) epi(row, col, acc[i][j][e]);
-      }
+  tile_epilogue(acc, ep, a.rem, b.rem, wm, wn, lane);
 }
 
 template <typename T>

@@ -4,6 +4,8 @@
 // on load (gptq.py:62).  The product is an exact-fp32 MFMA SYRK: only the upper
 // triangle tiles (ti <= tj) are formed -- H is symmetric -- which halves the
 // dominant FLOP term of the whole pipeline; gptq_symmetrize mirrors it on demand.
+#include <stdlib.h>
+
 #include "gemm_f32.h"
 
 namespace gptq {
@@ -24,11 +26,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void hessian_kernel(float* __restrict
   Operand<T> b{X + (long)tj * GBN, 1, ldx, min(GBN, C - tj * GBN), vec};
   float* Ht = H + (long)ti * GBM * ldh + (long)tj * GBN;
   const bool diag = ti == tj;
-  gemm_tile<T, T, false, false>(a, b, 0, tokens, smem, [=](int r, int c, float v) {
-    if (diag && r > c) return;
-    float* h = Ht + (long)r * ldh + c;
-    *h = alpha * *h + beta * v;   // contraction is off: fl(fl(alpha*h) + fl(beta*v))
-  });
+  gemm_tile<T, T, false, false>(a, b, 0, tokens, smem,
+                                Epilogue{Ht, ldh, 1, EPI_AXPBY, diag ? TRI_UPPER : TRI_ALL, alpha, beta});
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -191,20 +190,7 @@ __global__ __launch_bounds__(256) void hessian16_kernel(float* __restrict__ H, i
   }
 
   float* Ht = H + (long)ti * GBM * ldh + (long)tj * GBN;
-  const bool diag = ti == tj;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        const int col = wn * 64 + j * 32 + (lane & 31);
-        if (row < rem_a && col < rem_b && !(diag && row > col)) {
-          float* hp = Ht + (long)row * ldh + col;
-          *hp = alpha * *hp + beta * acc[i][j][e];
-        }
-      }
+  tile_epilogue(acc, Epilogue{Ht, ldh, 1, EPI_AXPBY, ti == tj ? TRI_UPPER : TRI_ALL, alpha, beta}, rem_a, rem_b, wm, wn, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -262,7 +248,7 @@ __device__ __forceinline__ s16x8 join8(frag_t lo, frag_t hi) {
 
 // Workgroup = 8 waves: waves 0-3 own the MFMA quadrants, waves 4-7 only issue LDS-DMA (an LDS-DMA
 // piece costs its wave ~100-185 cycles of issue; interleaved with the MFMAs it serialised them).
-template <bool BF16>
+template <bool BF16, int ABLATE = 0>   // ABLATE (diagnostic builds only): 1 = no MFMA side, 2 = no DMA
 __global__ __launch_bounds__(512) void hessian16_dma_kernel(float* __restrict__ H, int ldh,
                                                             const unsigned short* __restrict__ X, int ldx, int C,
                                                             int tokens, float alpha, float beta) {
@@ -289,7 +275,7 @@ __global__ __launch_bounds__(512) void hessian16_dma_kernel(float* __restrict__ 
       else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                           // stage kt landed; slot (kt-1) % RING is free
-      if (kt + RING - 1 < nk)
+      if (ABLATE != 2 && kt + RING - 1 < nk)
         dma_stage(Xa, Xb, ldx, (kt + RING - 1) * HBK, ring + ((kt + RING - 1) % RING) * DSTAGE, lw, lane);
     }
     return;
@@ -316,6 +302,7 @@ __global__ __launch_bounds__(512) void hessian16_dma_kernel(float* __restrict__ 
   const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)ring);
   for (int kt = 0; kt < nk; ++kt) {
     __builtin_amdgcn_s_barrier();                             // pairs with the loaders' barrier of stage kt
+    if (ABLATE == 1) continue;
     // Fragment reads go through inline asm: hipcc treats every LDS read as aliasing the in-flight
     // LDS-DMA and would drain it with vmcnt(0).  We order them ourselves: the counted vmcnt + barrier
     // above cover the DMA, lgkmcnt(0) + sched_barrier cover the reads (the MFMAs are register-only and
@@ -342,20 +329,7 @@ __global__ __launch_bounds__(512) void hessian16_dma_kernel(float* __restrict__ 
   }
 
   float* Ht = H + (long)ti * GBM * ldh + (long)tj * GBN;
-  const bool diag = ti == tj;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        const int col = wn * 64 + j * 32 + (lane & 31);
-        if (!(diag && row > col)) {
-          float* hp = Ht + (long)row * ldh + col;
-          *hp = alpha * *hp + beta * acc[i][j][e];
-        }
-      }
+  tile_epilogue(acc, Epilogue{Ht, ldh, 1, EPI_AXPBY, ti == tj ? TRI_UPPER : TRI_ALL, alpha, beta}, GBM, GBN, wm, wn, lane);
 }
 
 // A[r][c] = A[c][r] for r > c, through a 32x33 LDS tile so both sides stay coalesced.
@@ -405,7 +379,14 @@ extern "C" int gptq_hessian_accum(float* H, int ldh, const void* X, int x_dtype,
       const bool aligned = vec && (tokens % HBK == 0) && (C % GBM == 0);
       if (aligned) {
         const size_t lds = (size_t)RING * DSTAGE;
-        if (x_dtype == GPTQ_F16) {
+        static const int ablate = [] { const char* e = getenv("GPTQ_HESS_ABLATE"); return e ? atoi(e) : 0; }();
+        if (x_dtype == GPTQ_F16 && ablate == 1) {
+          GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_dma_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          hessian16_dma_kernel<false, 1><<<blocks, 512, lds, s>>>(H, ldh, x, ldx, C, tokens, alpha, beta);
+        } else if (x_dtype == GPTQ_F16 && ablate == 2) {
+          GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_dma_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          hessian16_dma_kernel<false, 2><<<blocks, 512, lds, s>>>(H, ldh, x, ldx, C, tokens, alpha, beta);
+        } else if (x_dtype == GPTQ_F16) {
           GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_dma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
           hessian16_dma_kernel<false><<<blocks, 512, lds, s>>>(H, ldh, x, ldx, C, tokens, alpha, beta);
         } else {
