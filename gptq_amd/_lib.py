@@ -22,6 +22,7 @@ _SIGNATURES = {
     "gptq_hip_abi_version": (C.c_int, []),
     "gptq_last_error": (C.c_char_p, []),
     "gptq_hessian_accum": (C.c_int, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "gptq_hessian_accum_multi": (C.c_int, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "gptq_symmetrize": (C.c_int, [_p, _i, _i, _p]),
     "gptq_find_params": (C.c_int, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _i, _p]),
     "gptq_quantize_rows": (C.c_int, [_p, _i, _i, _i, _p, _p, _i, _p]),

@@ -6,6 +6,8 @@
 // dominant FLOP term of the whole pipeline; gptq_symmetrize mirrors it on demand.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "gemm_f32.h"
 
 namespace gptq {
@@ -207,6 +209,8 @@ __global__ __launch_bounds__(256) void hessian16_kernel(float* __restrict__ H, i
 // ds_read_b64_tr_b16 conflict-free: the 4 rows x 4 chunks a half-wave touches land on 16 distinct chunks.
 // ---------------------------------------------------------------------------------------------
 constexpr int RING = 4;
+constexpr int MAX_XLIST = 16;
+struct XList { const unsigned short* p[MAX_XLIST]; };   // up to 16 equally shaped activation slabs per launch
 constexpr int DSTAGE = 2 * HBK * 256;        // bytes per ring slot: A + B, 64 rows x 256 B each
 
 __device__ __forceinline__ void dma_stage(const unsigned short* __restrict__ Xa, const unsigned short* __restrict__ Xb,
@@ -249,9 +253,9 @@ __device__ __forceinline__ s16x8 join8(frag_t lo, frag_t hi) {
 // Workgroup = 8 waves: waves 0-3 own the MFMA quadrants, waves 4-7 only issue LDS-DMA (an LDS-DMA
 // piece costs its wave ~100-185 cycles of issue; interleaved with the MFMAs it serialised them).
 template <bool BF16, int ABLATE = 0>   // ABLATE (diagnostic builds only): 1 = no MFMA side, 2 = no DMA
-__global__ __launch_bounds__(512) void hessian16_dma_kernel(float* __restrict__ H, int ldh,
-                                                            const unsigned short* __restrict__ X, int ldx, int C,
-                                                            int tokens, float alpha, float beta) {
+__global__ __launch_bounds__(512) void hessian16_dma_kernel(float* __restrict__ H, int ldh, XList xl, int nx,
+                                                            int ldx, int C, int tokens, float alpha, float beta) {
+  // `tokens` rows per slab, `nx` slabs: the K loop walks all of them (one H update for the whole batch)
   extern __shared__ __attribute__((aligned(1024))) char ring[];          // RING x DSTAGE, the ONLY LDS object
   const int nt = C / GBM;
   int ti, tj;
@@ -260,23 +264,27 @@ __global__ __launch_bounds__(512) void hessian16_dma_kernel(float* __restrict__ 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool loader = wave >= 4;                              // wave-uniform role
   const int wm = (wave >> 1) & 1, wn = wave & 1;
-  const unsigned short* Xa = X + (long)ti * GBM;
-  const unsigned short* Xb = X + (long)tj * GBN;
-  const int nk = tokens / HBK;
+  const int spk = tokens / HBK;                               // stages per slab
+  const int nk = spk * nx;
+  const long goffa = (long)ti * GBM, goffb = (long)tj * GBN;
+  auto issue = [&](int st, int lw) {
+    const int sl = st / spk;                                  // slab of this stage (wave-uniform)
+    const unsigned short* X = xl.p[sl];
+    dma_stage(X + goffa, X + goffb, ldx, (st - sl * spk) * HBK, ring + (st % RING) * DSTAGE, lw, lane);
+  };
 
   if (loader) {
     const int lw = wave - 4;
 #pragma unroll
     for (int st = 0; st < RING - 1; ++st)
-      if (st < nk) dma_stage(Xa, Xb, ldx, st * HBK, ring + st * DSTAGE, lw, lane);
+      if (st < nk) issue(st, lw);
     for (int kt = 0; kt < nk; ++kt) {
       const int ahead = min(RING - 2, nk - 1 - kt);           // stages issued after stage kt (uniform)
       if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                           // stage kt landed; slot (kt-1) % RING is free
-      if (ABLATE != 2 && kt + RING - 1 < nk)
-        dma_stage(Xa, Xb, ldx, (kt + RING - 1) * HBK, ring + ((kt + RING - 1) % RING) * DSTAGE, lw, lane);
+      if (ABLATE != 2 && kt + RING - 1 < nk) issue(kt + RING - 1, lw);
     }
     return;
   }
@@ -355,61 +363,86 @@ __global__ __launch_bounds__(256) void symmetrize_kernel(float* __restrict__ A, 
 
 using namespace gptq;
 
-extern "C" int gptq_hessian_accum(float* H, int ldh, const void* X, int x_dtype, int ldx, int C,
-                                  int tokens, int nsamples_before, int batch, gptq_stream_t stream) {
-  GPTQ_CHECK_ARG(H && X, "gptq_hessian_accum: null pointer");
-  GPTQ_CHECK_ARG(C > 0 && tokens > 0 && batch > 0 && nsamples_before >= 0, "gptq_hessian_accum: bad sizes");
-  GPTQ_CHECK_ARG(ldh >= C && ldx >= C, "gptq_hessian_accum: leading dimension smaller than C");
-  const int n_after = nsamples_before + batch;
-  const float alpha = (float)((double)nsamples_before / (double)n_after);   // gptq.py:59
-  const float beta = (float)(2.0 / (double)n_after);                        // gptq.py:62 squared
+// One H update for `n_x` equally shaped slabs X[i] [tokens, C] (row-major, ldx).
+static int hessian_launch(float* H, int ldh, const void* const* xs, int n_x, int x_dtype, int ldx, int C,
+                          int tokens, float alpha, float beta, hipStream_t s) {
   const int nt = cdiv(C, GBM);
   const int blocks = nt * (nt + 1) / 2;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  switch (x_dtype) {
-    case GPTQ_F32: {
-      const float* x = static_cast<const float*>(X);
-      hessian_kernel<float><<<blocks, GEMM_THREADS, 0, s>>>(H, ldh, x, ldx, C, tokens, alpha, beta, vec_ok(x, ldx));
-      break;
+  if (x_dtype == GPTQ_F16 || x_dtype == GPTQ_BF16) {
+    bool aligned = (ldx % 8 == 0) && (tokens % HBK == 0) && (C % GBM == 0);
+    for (int i = 0; i < n_x; ++i) aligned = aligned && (reinterpret_cast<uintptr_t>(xs[i]) % 16 == 0);
+    if (aligned) {
+      const size_t lds = (size_t)RING * DSTAGE;
+      static const int ablate = [] { const char* e = getenv("GPTQ_HESS_ABLATE"); return e ? atoi(e) : 0; }();
+      for (int i0 = 0; i0 < n_x; i0 += MAX_XLIST) {
+        XList xl{};
+        const int nx = std::min(MAX_XLIST, n_x - i0);
+        for (int i = 0; i < nx; ++i) xl.p[i] = static_cast<const unsigned short*>(xs[i0 + i]);
+        const float a = i0 == 0 ? alpha : 1.f;
+#define HDMA(BF, AB)                                                                                           \
+  do {                                                                                                         \
+    GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_dma_kernel<BF, AB>),           \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
+    hessian16_dma_kernel<BF, AB><<<blocks, 512, lds, s>>>(H, ldh, xl, nx, ldx, C, tokens, a, beta);            \
+  } while (0)
+        if (x_dtype == GPTQ_BF16) HDMA(true, 0);
+        else if (ablate == 1) HDMA(false, 1);
+        else if (ablate == 2) HDMA(false, 2);
+        else HDMA(false, 0);
+#undef HDMA
+      }
+      GPTQ_CHECK_LAUNCH("hessian16_dma_kernel");
+      return GPTQ_OK;
     }
-    case GPTQ_F16:
-    case GPTQ_BF16: {
-      const unsigned short* x = static_cast<const unsigned short*>(X);
-      const bool vec = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (ldx % 8 == 0);
-      const bool aligned = vec && (tokens % HBK == 0) && (C % GBM == 0);
-      if (aligned) {
-        const size_t lds = (size_t)RING * DSTAGE;
-        static const int ablate = [] { const char* e = getenv("GPTQ_HESS_ABLATE"); return e ? atoi(e) : 0; }();
-        if (x_dtype == GPTQ_F16 && ablate == 1) {
-          GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_dma_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          hessian16_dma_kernel<false, 1><<<blocks, 512, lds, s>>>(H, ldh, x, ldx, C, tokens, alpha, beta);
-        } else if (x_dtype == GPTQ_F16 && ablate == 2) {
-          GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_dma_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          hessian16_dma_kernel<false, 2><<<blocks, 512, lds, s>>>(H, ldh, x, ldx, C, tokens, alpha, beta);
-        } else if (x_dtype == GPTQ_F16) {
-          GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_dma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          hessian16_dma_kernel<false><<<blocks, 512, lds, s>>>(H, ldh, x, ldx, C, tokens, alpha, beta);
+  }
+  for (int i = 0; i < n_x; ++i) {
+    const float a = i == 0 ? alpha : 1.f;
+    switch (x_dtype) {
+      case GPTQ_F32: {
+        const float* x = static_cast<const float*>(xs[i]);
+        hessian_kernel<float><<<blocks, GEMM_THREADS, 0, s>>>(H, ldh, x, ldx, C, tokens, a, beta, vec_ok(x, ldx));
+        break;
+      }
+      case GPTQ_F16:
+      case GPTQ_BF16: {
+        const unsigned short* x = static_cast<const unsigned short*>(xs[i]);
+        const bool vec = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (ldx % 8 == 0);
+        const size_t lds = sizeof(unsigned short) * 4 * HTILE;
+        if (x_dtype == GPTQ_F16) {
+          GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          hessian16_kernel<false><<<blocks, 256, lds, s>>>(H, ldh, x, ldx, C, tokens, a, beta, vec);
         } else {
-          GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_dma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          hessian16_dma_kernel<true><<<blocks, 512, lds, s>>>(H, ldh, x, ldx, C, tokens, alpha, beta);
+          GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          hessian16_kernel<true><<<blocks, 256, lds, s>>>(H, ldh, x, ldx, C, tokens, a, beta, vec);
         }
         break;
       }
-      const size_t lds = sizeof(unsigned short) * 4 * HTILE;
-      if (x_dtype == GPTQ_F16) {
-        GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hessian16_kernel<false><<<blocks, 256, lds, s>>>(H, ldh, x, ldx, C, tokens, alpha, beta, vec);
-      } else {
-        GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hessian16_kernel<true><<<blocks, 256, lds, s>>>(H, ldh, x, ldx, C, tokens, alpha, beta, vec);
-      }
-      break;
+      default:
+        GPTQ_CHECK_ARG(false, "gptq_hessian_accum: unknown dtype %d", x_dtype);
     }
-    default:
-      GPTQ_CHECK_ARG(false, "gptq_hessian_accum: unknown dtype %d", x_dtype);
   }
   GPTQ_CHECK_LAUNCH("hessian_kernel");
   return GPTQ_OK;
+}
+
+extern "C" int gptq_hessian_accum_multi(float* H, int ldh, const void* const* X, int n_x, int x_dtype, int ldx,
+                                        int C, int tokens_each, int nsamples_before, int batch_total,
+                                        gptq_stream_t stream) {
+  GPTQ_CHECK_ARG(H && X && n_x > 0, "gptq_hessian_accum_multi: null pointer");
+  for (int i = 0; i < n_x; ++i) GPTQ_CHECK_ARG(X[i] != nullptr, "gptq_hessian_accum_multi: null slab %d", i);
+  GPTQ_CHECK_ARG(C > 0 && tokens_each > 0 && batch_total > 0 && nsamples_before >= 0, "gptq_hessian_accum_multi: bad sizes");
+  GPTQ_CHECK_ARG(ldh >= C && ldx >= C, "gptq_hessian_accum_multi: leading dimension smaller than C");
+  const int n_after = nsamples_before + batch_total;
+  const float alpha = (float)((double)nsamples_before / (double)n_after);   // gptq.py:59
+  const float beta = (float)(2.0 / (double)n_after);                        // gptq.py:62 squared
+  return hessian_launch(H, ldh, X, n_x, x_dtype, ldx, C, tokens_each, alpha, beta, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int gptq_hessian_accum(float* H, int ldh, const void* X, int x_dtype, int ldx, int C,
+                                  int tokens, int nsamples_before, int batch, gptq_stream_t stream) {
+  GPTQ_CHECK_ARG(X != nullptr, "gptq_hessian_accum: null pointer");
+  const void* xs[1] = {X};
+  return gptq_hessian_accum_multi(H, ldh, xs, 1, x_dtype, ldx, C, tokens, nsamples_before, batch, stream);
 }
 
 extern "C" int gptq_symmetrize(float* A, int lda, int n, gptq_stream_t stream) {

@@ -27,6 +27,12 @@ VERBOSE = True   # the reference prints `time` / `error` per layer (gptq.py:293-
 # The fork stores `self.input = mean(scaled batch)` in add_batch (gptq.py:63); only its out-of-scope
 # `analyse` / non_linear branches read it.  It costs an extra pass over X per call, so it is opt-in.
 TRACK_INPUT_MEAN = False
+# add_batch may hold up to HESSIAN_DEFER hook inputs (references, no copies) and fold them into H with
+# ONE launch -- the reference's own multi-sample batch formula (gptq.py:44, 59-65), so only rounding
+# differs.  It divides the fp32 H read-modify-write traffic and the per-tile pipeline fill by the
+# batch.  Requires that callers do not overwrite an activation in place after its hook returned (true
+# for the OPT / LLaMA blocks); 1 = apply every call immediately, exactly like the reference.
+HESSIAN_DEFER = 1
 
 
 class GPTQ:
@@ -45,10 +51,29 @@ class GPTQ:
         self._H = torch.zeros((self.columns, self.columns), device=self.dev, dtype=torch.float32)
         self._lower_stale = False   # add_batch maintains the upper triangle only
         self.nsamples = 0
+        self._pending = []          # deferred (x, batch) hook inputs, see HESSIAN_DEFER
+        self._applied = 0           # samples already folded into _H
 
     # -- H stays reachable as a full symmetric tensor; mirrored lazily -------------
+    def _flush(self):
+        if not self._pending:
+            return
+        import ctypes
+        xs = [x for x, _ in self._pending]
+        batch = sum(b for _, b in self._pending)
+        arr = (ctypes.c_void_p * len(xs))(*[x.data_ptr() for x in xs])
+        x0 = xs[0]
+        with torch.cuda.device(self.dev):
+            _lib.call("gptq_hessian_accum_multi", _lib.ptr(self._H), self._H.stride(0), arr, len(xs),
+                      _lib.dtype_code(x0), x0.stride(0), self.columns, x0.shape[0], int(self._applied), int(batch),
+                      _lib.stream(self.dev))
+        self._applied += batch
+        self._pending = []
+        self._lower_stale = True
+
     @property
     def H(self):
+        self._flush()
         if self._H is not None and self._lower_stale:
             with torch.cuda.device(self.dev):
                 _lib.call("gptq_symmetrize", _lib.ptr(self._H), self._H.stride(0), self.columns, _lib.stream(self.dev))
@@ -57,6 +82,7 @@ class GPTQ:
 
     @H.setter
     def H(self, value):
+        self._pending = []
         self._H = value
         self._lower_stale = False
 
@@ -85,11 +111,13 @@ class GPTQ:
             x = x.contiguous()
         if x.shape[1] != self.columns:
             raise ValueError(f"add_batch: input has {x.shape[1]} features, layer expects {self.columns}")
-        with torch.cuda.device(self.dev):
-            _lib.call("gptq_hessian_accum", _lib.ptr(self._H), self._H.stride(0), _lib.ptr(x), _lib.dtype_code(x),
-                      x.stride(0), self.columns, x.shape[0], int(self.nsamples), int(batch), _lib.stream(self.dev))
-        self._lower_stale = True
+        if self._pending and (self._pending[0][0].shape != x.shape or self._pending[0][0].dtype != x.dtype
+                              or self._pending[0][0].stride(0) != x.stride(0)):
+            self._flush()
+        self._pending.append((x, batch))
         self.nsamples += batch
+        if len(self._pending) >= max(1, int(HESSIAN_DEFER)):
+            self._flush()
         if TRACK_INPUT_MEAN:   # fork addition (gptq.py:63), unused by the default branch
             self.input = x.mean(0, dtype=torch.float32) * math.sqrt(2 / self.nsamples)
 
@@ -118,6 +146,8 @@ class GPTQ:
         dev = self.dev
 
         tick = time.time()
+        self._flush()
+        self._applied = self.nsamples if self.nsamples else self._applied
         H = self._H                      # upper triangle is all the solver reads
         self._H = None                   # consumed, like `del self.H` (gptq.py:141-142)
         if H is None:
@@ -174,6 +204,7 @@ class GPTQ:
             self.inp1 = None
             self.out1 = None
         self._H = None
+        self._pending = []
         self.Hinv = None
         self.codes = None
         self.Losses = None

@@ -44,6 +44,7 @@ class QuantArgs:
     nsamples: int = 128
     nearest: bool = False
     blocksize: int = 128
+    hessian_defer: int = 8      # hook inputs folded into H per launch (gptq_amd.gptq.HESSIAN_DEFER)
 
 
 class _Stop(Exception):
@@ -114,6 +115,8 @@ def _run_layer(layer, x, kwargs):
 @torch.no_grad()
 def quantize_sequential(model, dataloader, dev, args: QuantArgs) -> Dict[str, Quantizer]:
     """GPTQ every Linear of every decoder block; returns {full_name: quantizer} like the reference."""
+    from . import gptq as _gptq_mod
+    _gptq_mod.HESSIAN_DEFER = max(1, int(args.hessian_defer))
     use_cache = model.config.use_cache
     model.config.use_cache = False
     fam = _family(model)

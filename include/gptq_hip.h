@@ -48,6 +48,14 @@ const char* gptq_last_error(void);
 int gptq_hessian_accum(float* H, int ldh, const void* X, int x_dtype, int ldx, int C, int tokens,
                        int nsamples_before, int batch, gptq_stream_t stream);
 
+/* Same update for a batch of n_x equally shaped slabs X[i] [tokens_each, C] (X = HOST array of n_x
+ * device pointers) in ONE pass over H:  H <- H * n/(n+b) + (2/(n+b)) * sum_i X[i]^T X[i],
+ * b = batch_total samples -- gptq.py:42-65 with a multi-sample batch (tmp = b, gptq.py:44).
+ * Deferring several hook calls into one launch divides the fp32 H read-modify-write traffic by n_x. */
+int gptq_hessian_accum_multi(float* H, int ldh, const void* const* X, int n_x, int x_dtype, int ldx,
+                             int C, int tokens_each, int nsamples_before, int batch_total,
+                             gptq_stream_t stream);
+
 /* Mirror the upper triangle of A [n, n] into the lower triangle. */
 int gptq_symmetrize(float* A, int lda, int n, gptq_stream_t stream);
 

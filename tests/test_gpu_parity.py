@@ -543,3 +543,36 @@ def test_hessian_fp16_subnormal_inputs_are_not_flushed(G, hip_device):
     expect = 2.0 * S * (2.0 ** -40)
     got = gp.H.cpu()
     assert torch.allclose(got, torch.full_like(got, expect), rtol=1e-6, atol=0)
+
+
+def test_hessian_deferred_batches_match_immediate(G, O, hip_device):
+    """HESSIAN_DEFER folds several hook calls into one launch with the reference's multi-sample batch
+    formula (gptq.py:44, 59-65): same H up to rounding, `nsamples` bookkeeping unchanged."""
+    import gptq_amd.gptq as gmod
+    gen = torch.Generator().manual_seed(23)
+    C, S = 256, 128
+    xs = [(torch.randn(1, S, C, generator=gen) * (1 + torch.arange(C) % 7)).half() for _ in range(7)]
+    Href = torch.zeros(C, C)
+    n = 0
+    for x in xs:
+        n = O.hessian_add_batch(Href, n, x)
+    old = gmod.HESSIAN_DEFER
+    try:
+        for defer in (1, 3, 8):
+            gmod.HESSIAN_DEFER = defer
+            gp = G.GPTQ(make_linear(torch.zeros(4, C, device=hip_device)))
+            for k, x in enumerate(xs):
+                gp.add_batch(x.cuda(), None)
+                assert gp.nsamples == k + 1
+            assert relfro(gp.H.cpu(), Href) <= 1e-6, defer
+            # a different shape in the middle forces a flush but stays correct
+            gp2 = G.GPTQ(make_linear(torch.zeros(4, C, device=hip_device)))
+            gp2.add_batch(xs[0].cuda(), None)
+            gp2.add_batch(xs[1][:, :64].cuda(), None)
+            gp2.add_batch(xs[2].cuda(), None)
+            H2 = torch.zeros(C, C); m = 0
+            for x in (xs[0], xs[1][:, :64], xs[2]):
+                m = O.hessian_add_batch(H2, m, x)
+            assert relfro(gp2.H.cpu(), H2) <= 1e-6
+    finally:
+        gmod.HESSIAN_DEFER = old
