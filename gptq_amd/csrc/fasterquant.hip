@@ -248,6 +248,9 @@ __global__ __launch_bounds__(256) void quant_block_kernel(QuantBlockArgs a) {
         gz4[0] = quad_bcast<0>(pzr[t]); gz4[1] = quad_bcast<1>(pzr[t]);
         gz4[2] = quad_bcast<2>(pzr[t]); gz4[3] = quad_bcast<3>(pzr[t]);
       }
+      // (a) the dependent chain of the four columns of this super-step: quantize, error, and the
+      //     update of the not-yet-quantized columns of the SAME super-step (quad-uniform values)
+      float err4[4];
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) {
         const int il = 4 * t + cc;
@@ -260,17 +263,25 @@ __global__ __launch_bounds__(256) void quant_block_kernel(QuantBlockArgs a) {
         const float q = gsc * (code - gzr);
         const float d = urow[cc * LDCL + 8 * ph + t];            // Hinv1[i, i]
         const float err = (x - q) / d;                           // gptq.py:269
+        err4[cc] = err;
         loss += err * err;                                       // (w-q)^2/d^2, gptq.py:267 (tolerance-level)
         if (c == cc) { w[t] = q; e[t] = err; cd[t] = code; }
 #pragma unroll
-        for (int c2 = cc + 1; c2 < 4; ++c2)                      // rest of this super-step (uniform)
+        for (int c2 = cc + 1; c2 < 4; ++c2)
           cur[c2] -= err * urow[c2 * LDCL + 8 * ph + t];         // gptq.py:270
-        const float* ul = urow + c * LDCL + 8 * ph;
+      }
+      // (b) the four rank-1 updates of every later column, applied per element in the reference's
+      //     order (column i, then i+1, ...): independent across elements, so the LDS reads batch up
+      //     and nothing here sits on the chain above.
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const float* ul = Us + (4 * t + cc) * 4 * LDCL + c * LDCL + 8 * ph;
+        const float err = err4[cc];
 #pragma unroll
         for (int t2 = t + 1; t2 < 8; ++t2) w[t2] -= err * ul[t2];
 #pragma unroll
         for (int g = 1; g < NPH; ++g) {
-          if (ph + g < NPH) {                                    // block-uniform
+          if (ph + g < NPH) {                                    // static after unrolling
 #pragma unroll
             for (int t2 = 0; t2 < 8; ++t2) w[8 * g + t2] -= err * ul[8 * g + t2];
           }
