@@ -167,6 +167,110 @@ struct QuantBlockArgs {
   float* Err; uint8_t* codes; int ldc; const int32_t* col_map; float* loss;
 };
 
+// One 32-column phase PH of the block (compile-time, so every "is there a later group" test and every
+// register index below is static: no branches inside, no register shuffling between phases).
+template <int NPH, bool GROUPED, int PH>
+__device__ __forceinline__ void quant_phase(const QuantBlockArgs& a, float (&w)[8 * NPH], float* Us,
+                                            const int* grp, const int* cmap, float sc, float zr, bool active,
+                                            long rbase, float* wrow, int c, int tid, float& loss) {
+  constexpr int B = 32 * NPH;
+  constexpr int NREG = 8 * NPH;
+  constexpr int LDCL = NREG + 4;
+  constexpr int ph = PH;
+  __syncthreads();
+  // stage the 32 U rows of this phase: Us[il][k & 3][k >> 2] = U[i][k], k >= i (upper), else 0
+  for (int idx = tid; idx < 32 * B; idx += 256) {
+    const int il = idx / B, k = idx % B;
+    const int i = 32 * ph + il;
+    // columns past `count` (tail block) are padded: zero weights, identity U rows and a unit grid
+    // make their steps exact no-ops, so the hot loop below carries no `count` branches
+    float v = (k == i) ? 1.f : 0.f;
+    if (i < a.count && k >= i && k < a.count) v = a.U[(long)(a.i1 + i) * a.ldu + a.i1 + k];
+    Us[(il * 4 + (k & 3)) * LDCL + (k >> 2)] = v;
+  }
+  __syncthreads();
+
+  float e[8], cd[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) { e[t] = 0.f; cd[t] = 0.f; }
+
+  // grids of this phase's 32 columns: lane c fetches those of columns 4t + c up front (all loads in
+  // flight together, off the sequential chain) and the quad shares them by DPP at each step
+  float psc[8], pzr[8];
+  if (GROUPED) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int col = 32 * ph + 4 * t + c;
+      const int g = grp[min(col, B - 1)];
+      psc[t] = (active && col < a.count) ? a.scale_tab[rbase * a.tab_ld + g] : 1.f;
+      pzr[t] = (active && col < a.count) ? a.zero_tab[rbase * a.tab_ld + g] : 0.f;
+    }
+  }
+  const bool tail = !GROUPED && (32 * ph + 32 > a.count);   // block-uniform, false except in a tail block
+
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    float* wt = &w[8 * ph];                                    // this phase's window of registers
+    float cur[4];
+    cur[0] = quad_bcast<0>(wt[t]);
+    cur[1] = quad_bcast<1>(wt[t]);
+    cur[2] = quad_bcast<2>(wt[t]);
+    cur[3] = quad_bcast<3>(wt[t]);
+    float gs4[4], gz4[4];
+    if (GROUPED) {
+      gs4[0] = quad_bcast<0>(psc[t]); gs4[1] = quad_bcast<1>(psc[t]);
+      gs4[2] = quad_bcast<2>(psc[t]); gs4[3] = quad_bcast<3>(psc[t]);
+      gz4[0] = quad_bcast<0>(pzr[t]); gz4[1] = quad_bcast<1>(pzr[t]);
+      gz4[2] = quad_bcast<2>(pzr[t]); gz4[3] = quad_bcast<3>(pzr[t]);
+    }
+    // (a) the dependent chain of the four columns of this super-step: quantize, error, and the
+    //     update of the not-yet-quantized columns of the SAME super-step (quad-uniform values)
+    float err4[4];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      const int il = 4 * t + cc;
+      float gsc = sc, gzr = zr;
+      if (GROUPED) { gsc = gs4[cc]; gzr = gz4[cc]; }
+      else if (tail && 32 * ph + il >= a.count) { gsc = 1.f; gzr = 0.f; }
+      const float* urow = Us + il * 4 * LDCL;
+      const float x = cur[cc];
+      const float code = affine_code(x, gsc, gzr, a.maxq);     // gptq.py:262-264
+      const float q = gsc * (code - gzr);
+      const float d = urow[cc * LDCL + 8 * ph + t];            // Hinv1[i, i]
+      const float err = (x - q) / d;                           // gptq.py:269
+      err4[cc] = err;
+      loss += err * err;                                       // (w-q)^2/d^2, gptq.py:267 (tolerance-level)
+      if (c == cc) { wt[t] = q; e[t] = err; cd[t] = code; }
+#pragma unroll
+      for (int c2 = cc + 1; c2 < 4; ++c2)
+        cur[c2] -= err * urow[c2 * LDCL + 8 * ph + t];         // gptq.py:270
+    }
+    // (b) the four rank-1 updates of every later column, applied per element in the reference's
+    //     order (column i, then i+1, ...): independent across elements, so the LDS reads batch up
+    //     and nothing here sits on the chain above.
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      const float* ul = Us + (4 * t + cc) * 4 * LDCL + c * LDCL;
+      const float err = err4[cc];
+#pragma unroll
+      for (int j = 8 * ph + t + 1; j < NREG; ++j) w[j] -= err * ul[j];
+    }
+  }
+
+  // retire the window: Q1 -> W, Err1 -> Err, codes
+  if (active) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int col = 32 * ph + 4 * t + c;
+      if (col < a.count) {
+        wrow[col] = w[8 * ph + t];
+        if (a.codes) a.codes[rbase * a.ldc + cmap[col]] = (uint8_t)cd[t];
+      }
+      a.Err[rbase * B + col] = (col < a.count) ? e[t] : 0.f;
+    }
+  }
+}
+
 template <int NPH, bool GROUPED>
 __global__ __launch_bounds__(256) void quant_block_kernel(QuantBlockArgs a) {
   constexpr int B = 32 * NPH;
@@ -201,109 +305,9 @@ __global__ __launch_bounds__(256) void quant_block_kernel(QuantBlockArgs a) {
   }
   float loss = 0.f;
 
-#pragma unroll
-  for (int ph = 0; ph < NPH; ++ph) {      // fully unrolled: the register slide below is pure renaming
-    __syncthreads();
-    // stage the 32 U rows of this phase: Us[il][k & 3][k >> 2] = U[i][k], k >= i (upper), else 0
-    for (int idx = tid; idx < 32 * B; idx += 256) {
-      const int il = idx / B, k = idx % B;
-      const int i = 32 * ph + il;
-      // columns past `count` (tail block) are padded: zero weights, identity U rows and a unit grid
-      // make their steps exact no-ops, so the hot loop below carries no `count` branches
-      float v = (k == i) ? 1.f : 0.f;
-      if (i < a.count && k >= i && k < a.count) v = a.U[(long)(a.i1 + i) * a.ldu + a.i1 + k];
-      Us[(il * 4 + (k & 3)) * LDCL + (k >> 2)] = v;
-    }
-    __syncthreads();
-
-    float e[8], cd[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) { e[t] = 0.f; cd[t] = 0.f; }
-
-    // grids of this phase's 32 columns: lane c fetches those of columns 4t + c up front (all loads in
-    // flight together, off the sequential chain) and the quad shares them by DPP at each step
-    float psc[8], pzr[8];
-    if (GROUPED) {
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const int col = 32 * ph + 4 * t + c;
-        const int g = grp[min(col, B - 1)];
-        psc[t] = (active && col < a.count) ? a.scale_tab[rbase * a.tab_ld + g] : 1.f;
-        pzr[t] = (active && col < a.count) ? a.zero_tab[rbase * a.tab_ld + g] : 0.f;
-      }
-    }
-    const bool tail = !GROUPED && (32 * ph + 32 > a.count);   // block-uniform, false except in a tail block
-
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      float cur[4];
-      cur[0] = quad_bcast<0>(w[t]);
-      cur[1] = quad_bcast<1>(w[t]);
-      cur[2] = quad_bcast<2>(w[t]);
-      cur[3] = quad_bcast<3>(w[t]);
-      float gs4[4], gz4[4];
-      if (GROUPED) {
-        gs4[0] = quad_bcast<0>(psc[t]); gs4[1] = quad_bcast<1>(psc[t]);
-        gs4[2] = quad_bcast<2>(psc[t]); gs4[3] = quad_bcast<3>(psc[t]);
-        gz4[0] = quad_bcast<0>(pzr[t]); gz4[1] = quad_bcast<1>(pzr[t]);
-        gz4[2] = quad_bcast<2>(pzr[t]); gz4[3] = quad_bcast<3>(pzr[t]);
-      }
-      // (a) the dependent chain of the four columns of this super-step: quantize, error, and the
-      //     update of the not-yet-quantized columns of the SAME super-step (quad-uniform values)
-      float err4[4];
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) {
-        const int il = 4 * t + cc;
-        float gsc = sc, gzr = zr;
-        if (GROUPED) { gsc = gs4[cc]; gzr = gz4[cc]; }
-        else if (tail && 32 * ph + il >= a.count) { gsc = 1.f; gzr = 0.f; }
-        const float* urow = Us + il * 4 * LDCL;
-        const float x = cur[cc];
-        const float code = affine_code(x, gsc, gzr, a.maxq);     // gptq.py:262-264
-        const float q = gsc * (code - gzr);
-        const float d = urow[cc * LDCL + 8 * ph + t];            // Hinv1[i, i]
-        const float err = (x - q) / d;                           // gptq.py:269
-        err4[cc] = err;
-        loss += err * err;                                       // (w-q)^2/d^2, gptq.py:267 (tolerance-level)
-        if (c == cc) { w[t] = q; e[t] = err; cd[t] = code; }
-#pragma unroll
-        for (int c2 = cc + 1; c2 < 4; ++c2)
-          cur[c2] -= err * urow[c2 * LDCL + 8 * ph + t];         // gptq.py:270
-      }
-      // (b) the four rank-1 updates of every later column, applied per element in the reference's
-      //     order (column i, then i+1, ...): independent across elements, so the LDS reads batch up
-      //     and nothing here sits on the chain above.
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) {
-        const float* ul = Us + (4 * t + cc) * 4 * LDCL + c * LDCL + 8 * ph;
-        const float err = err4[cc];
-#pragma unroll
-        for (int t2 = t + 1; t2 < 8; ++t2) w[t2] -= err * ul[t2];
-#pragma unroll
-        for (int g = 1; g < NPH; ++g) {
-          if (ph + g < NPH) {                                    // static after unrolling
-#pragma unroll
-            for (int t2 = 0; t2 < 8; ++t2) w[8 * g + t2] -= err * ul[8 * g + t2];
-          }
-        }
-      }
-    }
-
-    // retire the window: Q1 -> W, Err1 -> Err, codes; then slide the registers down by one window
-    if (active) {
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const int col = 32 * ph + 4 * t + c;
-        if (col < a.count) {
-          wrow[col] = w[t];
-          if (a.codes) a.codes[rbase * a.ldc + cmap[col]] = (uint8_t)cd[t];
-        }
-        a.Err[rbase * B + col] = (col < a.count) ? e[t] : 0.f;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j + 8 < NREG; ++j) w[j] = w[j + 8];
-  }
+#define QPHASE(P) if constexpr (NPH > P) quant_phase<NPH, GROUPED, P>(a, w, Us, grp, cmap, sc, zr, active, rbase, wrow, c, tid, loss)
+  QPHASE(0); QPHASE(1); QPHASE(2); QPHASE(3); QPHASE(4); QPHASE(5); QPHASE(6); QPHASE(7);
+#undef QPHASE
   if (active && c == 0) a.loss[row] += 0.5f * loss;               // gptq.py:274
 }
 
