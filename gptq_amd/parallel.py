@@ -81,8 +81,14 @@ def allgather_packed(local: Dict[int, Tuple[torch.Tensor, torch.Tensor, torch.Te
         for t in (q.reshape(-1), s.reshape(-1).float().view(torch.int32), z.reshape(-1).float().view(torch.int32)):
             send[off:off + t.numel()] = t
             off += t.numel()
-    recv = torch.empty(world * width, dtype=torch.int32, device=device)
-    dist.all_gather_into_tensor(recv, send, group=group)
+    if device.type == "cuda" and dist.get_backend(group) != "nccl":
+        # rehearsal backends (gloo): stage through host memory
+        host = torch.empty(world * width, dtype=torch.int32)
+        dist.all_gather_into_tensor(host, send.cpu(), group=group)
+        recv = host.to(device)
+    else:
+        recv = torch.empty(world * width, dtype=torch.int32, device=device)
+        dist.all_gather_into_tensor(recv, send, group=group)
     out: Dict[int, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = {}
     for r in range(world):
         off = r * width
