@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void hessian16_kernel(float* __restrict__ H, i
 // The swizzle lives on the per-lane SOURCE address of the DMA and on the transposed read, and makes
 // ds_read_b64_tr_b16 conflict-free: the 4 rows x 4 chunks a half-wave touches land on 16 distinct chunks.
 // ---------------------------------------------------------------------------------------------
-constexpr int RING = 4;
+constexpr int RING_DEFAULT = 4;
 constexpr int MAX_XLIST = 16;
 struct XList { const unsigned short* p[MAX_XLIST]; };   // up to 16 equally shaped activation slabs per launch
 constexpr int DSTAGE = 2 * HBK * 256;        // bytes per ring slot: A + B, 64 rows x 256 B each
@@ -252,7 +252,7 @@ __device__ __forceinline__ s16x8 join8(frag_t lo, frag_t hi) {
 
 // Workgroup = 8 waves: waves 0-3 own the MFMA quadrants, waves 4-7 only issue LDS-DMA (an LDS-DMA
 // piece costs its wave ~100-185 cycles of issue; interleaved with the MFMAs it serialised them).
-template <bool BF16, int ABLATE = 0>   // ABLATE (diagnostic builds only): 1 = no MFMA side, 2 = no DMA
+template <bool BF16, int ABLATE = 0, int RING = RING_DEFAULT>   // ABLATE (diagnostic builds only): 1 = no MFMA side, 2 = no DMA
 __global__ __launch_bounds__(512) void hessian16_dma_kernel(float* __restrict__ H, int ldh, XList xl, int nx,
                                                             int ldx, int C, int tokens, float alpha, float beta) {
   // `tokens` rows per slab, `nx` slabs: the K loop walks all of them (one H update for the whole batch)
@@ -317,16 +317,18 @@ __global__ __launch_bounds__(512) void hessian16_dma_kernel(float* __restrict__ 
     // would otherwise be hoisted above the wait).  Reads of k-step kk+1 fly under the MFMAs of kk.
     const unsigned sbase = lds0 + (kt % RING) * DSTAGE;
     const unsigned aa0 = sbase + offa[0], aa1 = sbase + offa[1], ab0 = sbase + offb[0], ab1 = sbase + offb[1];
-    frag_t f[2][8];
+    frag_t f[3][8];                                            // fragment reads run TWO k-steps ahead
     TR_READ_STEP(f[0], 0);
+    TR_READ_STEP(f[1], 1);
 #pragma unroll
     for (int kk = 0; kk < HBK / 16; ++kk) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // LDS reads return in order: allow the 8 reads of k-step kk+1 to stay in flight
+      if (kk < HBK / 16 - 1) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
-      if (kk == 0) { TR_READ_STEP(f[1], 1); }
-      else if (kk == 1) { TR_READ_STEP(f[0], 2); }
-      else if (kk == 2) { TR_READ_STEP(f[1], 3); }
-      const frag_t* c = f[kk & 1];
+      if (kk == 0) { TR_READ_STEP(f[2], 2); }
+      else if (kk == 1) { TR_READ_STEP(f[0], 3); }
+      const frag_t* c = f[kk % 3];
       const s16x8 fa0 = join8(c[0], c[1]), fa1 = join8(c[2], c[3]);
       const s16x8 fb0 = join8(c[4], c[5]), fb1 = join8(c[6], c[7]);
       acc[0][0] = mfma16<BF16>(fa0, fb0, acc[0][0]);
@@ -372,7 +374,8 @@ static int hessian_launch(float* H, int ldh, const void* const* xs, int n_x, int
     bool aligned = (ldx % 8 == 0) && (tokens % HBK == 0) && (C % GBM == 0);
     for (int i = 0; i < n_x; ++i) aligned = aligned && (reinterpret_cast<uintptr_t>(xs[i]) % 16 == 0);
     if (aligned) {
-      const size_t lds = (size_t)RING * DSTAGE;
+      static const int ring_env = [] { const char* e = getenv("GPTQ_HESS_RING"); return e ? atoi(e) : RING_DEFAULT; }();
+      const size_t lds = (size_t)ring_env * DSTAGE;
       static const int ablate = [] { const char* e = getenv("GPTQ_HESS_ABLATE"); return e ? atoi(e) : 0; }();
       for (int i0 = 0; i0 < n_x; i0 += MAX_XLIST) {
         XList xl{};
@@ -385,7 +388,13 @@ static int hessian_launch(float* H, int ldh, const void* const* xs, int n_x, int
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
     hessian16_dma_kernel<BF, AB><<<blocks, 512, lds, s>>>(H, ldh, xl, nx, ldx, C, tokens, a, beta);            \
   } while (0)
-        if (x_dtype == GPTQ_BF16) HDMA(true, 0);
+        if (x_dtype == GPTQ_F16 && ring_env == 2) {
+          GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_dma_kernel<false, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          hessian16_dma_kernel<false, 0, 2><<<blocks, 512, lds, s>>>(H, ldh, xl, nx, ldx, C, tokens, a, beta);
+        } else if (x_dtype == GPTQ_F16 && ring_env == 3) {
+          GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_dma_kernel<false, 0, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          hessian16_dma_kernel<false, 0, 3><<<blocks, 512, lds, s>>>(H, ldh, xl, nx, ldx, C, tokens, a, beta);
+        } else if (x_dtype == GPTQ_BF16) HDMA(true, 0);
         else if (ablate == 1) HDMA(false, 1);
         else if (ablate == 2) HDMA(false, 2);
         else HDMA(false, 0);
