@@ -5,7 +5,7 @@ call does, and fails loudly if the library was not built (`python -m gptq_amd.bu
 """
 from .gptq import GPTQ  # noqa: F401
 from .modelutils import DEV, find_layers  # noqa: F401
-from .quant import (Quant3Linear, Quant4Linear, Quantizer, make_quant3, make_quant4,  # noqa: F401
-                    pack_codes, quantize)
+from .quant import (Quant3Linear, Quant4Linear, QuantGroupLinear, Quantizer, make_quant3,  # noqa: F401
+                    make_quant4, pack_codes, quantize)
 
 __version__ = "0.1.0"

@@ -36,6 +36,7 @@ _SIGNATURES = {
     "gptq_pack_codes": (C.c_int, [_p, _i, _i, _i, _i, _p, _p]),
     "gptq_vecquant3matmul": (C.c_int, [_p, _i, _p, _p, _p, _p, _i, _i, _p]),
     "gptq_vecquant4matmul": (C.c_int, [_p, _i, _p, _p, _p, _p, _i, _i, _p]),
+    "gptq_vecquant_matmul_grouped": (C.c_int, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

@@ -47,12 +47,16 @@ template <> __device__ __forceinline__ float mv_to_f32<float>(float v) { return 
 template <> __device__ __forceinline__ float mv_to_f32<__half>(__half v) { return __half2float(v); }
 
 // VW = output columns per thread (4: 16-byte loads; 1: fallback for width % 4 != 0)
+// groupsize == 0: one (scale, zero) per output column ([width]), applied once per workgroup.
+// groupsize  > 0: grouped grids, tables [in/groupsize, width] (row = group), applied per 32-input group:
+//                 y += s[g][col] * sum_{k in group}(q x) - z[g][col] * sum_{k in group}(x)   (SURVEY row f4).
 template <int BITS, int VW, typename TV>
 __global__ __launch_bounds__(256) void matvec_kernel(const TV* __restrict__ vec, const int32_t* __restrict__ mat,
                                                      float* __restrict__ mul, const float* __restrict__ scales,
                                                      const float* __restrict__ zeros, int ngroups, int width,
-                                                     int kgroups) {
+                                                     int kgroups, int groupsize) {
   __shared__ __attribute__((aligned(16))) float xs[MV_KGROUPS_MAX * 32];
+  __shared__ float xs32[MV_KGROUPS_MAX];
   __shared__ float red[4][64 * VW + 1];
   __shared__ float xsum_s[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -71,6 +75,15 @@ __global__ __launch_bounds__(256) void matvec_kernel(const TV* __restrict__ vec,
   for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
   if (lane == 0) xsum_s[wave] = part;
   __syncthreads();
+  if (groupsize > 0) {                                   // per-32-group sums of x for the grouped zero term
+    for (int g = tid; g < kgroups; g += 256) {
+      float sx = 0.f;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) sx += xs[g * 32 + j];
+      xs32[g] = sx;
+    }
+    __syncthreads();
+  }
 
   float acc[VW];
 #pragma unroll
@@ -92,9 +105,18 @@ __global__ __launch_bounds__(256) void matvec_kernel(const TV* __restrict__ vec,
     uint32_t wa[BITS][VW], wb[BITS][VW];
     int g = wave;
     if (g < ng) fetch(g, wa);
+    float tot[VW];
+#pragma unroll
+    for (int v = 0; v < VW; ++v) tot[v] = 0.f;
     while (g < ng) {
       const bool more = g + 4 < ng;
       if (more) fetch(g + 4, wb);
+      float sg[VW], zg[VW];
+      if (groupsize > 0) {
+        const long trow = (long)(((g0 + g) * 32) / groupsize) * width + col;
+#pragma unroll
+        for (int v = 0; v < VW; ++v) { sg[v] = scales[trow + v]; zg[v] = zeros[trow + v]; acc[v] = 0.f; }
+      }
 #pragma unroll
       for (int v = 0; v < VW; ++v) {
         uint32_t wc[BITS];
@@ -102,11 +124,20 @@ __global__ __launch_bounds__(256) void matvec_kernel(const TV* __restrict__ vec,
         for (int r = 0; r < BITS; ++r) wc[r] = wa[r][v];
         dot_group<BITS>(wc, xs + g * 32, acc[v]);
       }
+      if (groupsize > 0) {
+        const float sx = xs32[g];
+#pragma unroll
+        for (int v = 0; v < VW; ++v) tot[v] += sg[v] * acc[v] - zg[v] * sx;
+      }
 #pragma unroll
       for (int r = 0; r < BITS; ++r)
 #pragma unroll
         for (int v = 0; v < VW; ++v) wa[r][v] = wb[r][v];
       g += 4;
+    }
+    if (groupsize > 0) {
+#pragma unroll
+      for (int v = 0; v < VW; ++v) acc[v] = tot[v];
     }
   }
 #pragma unroll
@@ -116,15 +147,20 @@ __global__ __launch_bounds__(256) void matvec_kernel(const TV* __restrict__ vec,
     const int c = blockIdx.x * 64 * VW + tid;
     if (c < width) {
       const float q = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-      const float sx = xsum_s[0] + xsum_s[1] + xsum_s[2] + xsum_s[3];
-      atomicAdd(&mul[c], scales[c] * q - zeros[c] * sx);
+      if (groupsize > 0) {
+        atomicAdd(&mul[c], q);
+      } else {
+        const float sx = xsum_s[0] + xsum_s[1] + xsum_s[2] + xsum_s[3];
+        atomicAdd(&mul[c], scales[c] * q - zeros[c] * sx);
+      }
     }
   }
 }
 
 template <int BITS>
 static int launch_matvec(const void* vec, int vec_dtype, const int32_t* mat, float* mul, const float* scales,
-                         const float* zeros, int height, int width, hipStream_t s, const char* who) {
+                         const float* zeros, int height, int width, int groupsize, hipStream_t s, const char* who) {
+  GPTQ_CHECK_ARG(groupsize == 0 || (groupsize > 0 && groupsize % 32 == 0), "%s: groupsize must be a multiple of 32", who);
   GPTQ_CHECK_ARG(vec && mat && mul && scales && zeros, "%s: null pointer", who);
   GPTQ_CHECK_ARG(height > 0 && width > 0 && height % BITS == 0, "%s: height must be a positive multiple of %d", who, BITS);
   GPTQ_CHECK_ARG(vec_dtype == GPTQ_F32 || vec_dtype == GPTQ_F16, "%s: vec must be fp32 or fp16", who);
@@ -136,7 +172,7 @@ static int launch_matvec(const void* vec, int vec_dtype, const int32_t* mat, flo
   const dim3 grid(cdiv(width, 64 * vw), cdiv(ngroups, kgroups));
   GPTQ_CHECK_ARG(grid.y <= 65535, "%s: too many input groups", who);
 #define MV_LAUNCH(VW, TV) \
-  matvec_kernel<BITS, VW, TV><<<grid, 256, 0, s>>>(static_cast<const TV*>(vec), mat, mul, scales, zeros, ngroups, width, kgroups)
+  matvec_kernel<BITS, VW, TV><<<grid, 256, 0, s>>>(static_cast<const TV*>(vec), mat, mul, scales, zeros, ngroups, width, kgroups, groupsize)
   if (vec_dtype == GPTQ_F32) { if (v4) MV_LAUNCH(4, float); else MV_LAUNCH(1, float); }
   else { if (v4) MV_LAUNCH(4, __half); else MV_LAUNCH(1, __half); }
 #undef MV_LAUNCH
@@ -151,13 +187,26 @@ using namespace gptq;
 extern "C" int gptq_vecquant3matmul(const void* vec, int vec_dtype, const int32_t* mat, float* mul,
                                     const float* scales, const float* zeros, int height, int width,
                                     gptq_stream_t stream) {
-  return launch_matvec<3>(vec, vec_dtype, mat, mul, scales, zeros, height, width,
+  return launch_matvec<3>(vec, vec_dtype, mat, mul, scales, zeros, height, width, 0,
                           static_cast<hipStream_t>(stream), "gptq_vecquant3matmul");
 }
 
 extern "C" int gptq_vecquant4matmul(const void* vec, int vec_dtype, const int32_t* mat, float* mul,
                                     const float* scales, const float* zeros, int height, int width,
                                     gptq_stream_t stream) {
-  return launch_matvec<4>(vec, vec_dtype, mat, mul, scales, zeros, height, width,
+  return launch_matvec<4>(vec, vec_dtype, mat, mul, scales, zeros, height, width, 0,
                           static_cast<hipStream_t>(stream), "gptq_vecquant4matmul");
+}
+
+extern "C" int gptq_vecquant_matmul_grouped(const void* vec, int vec_dtype, const int32_t* mat, float* mul,
+                                            const float* scales, const float* zeros, int height, int width,
+                                            int bits, int groupsize, gptq_stream_t stream) {
+  GPTQ_CHECK_ARG(bits == 3 || bits == 4, "gptq_vecquant_matmul_grouped: bits must be 3 or 4");
+  GPTQ_CHECK_ARG(groupsize > 0, "gptq_vecquant_matmul_grouped: groupsize must be positive");
+  GPTQ_CHECK_ARG((height / bits * 32) % groupsize == 0, "gptq_vecquant_matmul_grouped: in_features must be a multiple of groupsize");
+  if (bits == 3)
+    return launch_matvec<3>(vec, vec_dtype, mat, mul, scales, zeros, height, width, groupsize,
+                            static_cast<hipStream_t>(stream), "gptq_vecquant_matmul_grouped");
+  return launch_matvec<4>(vec, vec_dtype, mat, mul, scales, zeros, height, width, groupsize,
+                          static_cast<hipStream_t>(stream), "gptq_vecquant_matmul_grouped");
 }

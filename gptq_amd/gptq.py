@@ -194,6 +194,7 @@ class GPTQ:
         self.codes = codes
         self.group_scale, self.group_zero = gscale, gzero
         self.perm = perm
+        self.static_groups = bool(static_groups)
         Q = W
         if _Conv1D and isinstance(self.layer, _Conv1D):
             Q = Q.t()

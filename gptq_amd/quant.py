@@ -208,6 +208,56 @@ class Quant4Linear(_QuantLinearBase):
         quant_cuda.vecquant4matmul(x, self.qweight, y, self.scales, self.zeros)
 
 
+class QuantGroupLinear(nn.Module):
+    """Packed Linear with one (scale, zero) per `groupsize` input columns.
+
+    The reference cannot pack grouped models (Quant3Linear keeps per-row scalars, quant.py:144-145, and
+    fasterquant leaves only the LAST group's grid in the quantizer).  Buffers: `qweight` int32
+    [in/32*bits, out] (same bit layouts as the per-row modules, original column order), `scales` /
+    `zeros` fp32 [in/groupsize, out] (`zeros` = zero*scale), `bias`.  Filled from a finished `GPTQ`
+    object (`codes`, `group_scale`, `group_zero`); valid for static groups or runs without act-order.
+    """
+
+    def __init__(self, bits, groupsize, infeatures, outfeatures):
+        super().__init__()
+        if bits not in (3, 4) or groupsize % 32 or infeatures % groupsize:
+            raise ValueError("QuantGroupLinear: bits in {3,4}, groupsize % 32 == 0, in_features % groupsize == 0")
+        self.bits, self.groupsize = bits, groupsize
+        self.register_buffer('qweight', torch.zeros((infeatures // 32 * bits, outfeatures), dtype=torch.int))
+        self.register_buffer('scales', torch.zeros((infeatures // groupsize, outfeatures)))
+        self.register_buffer('zeros', torch.zeros((infeatures // groupsize, outfeatures)))
+        self.register_buffer('bias', torch.zeros(outfeatures))
+
+    @classmethod
+    def from_gptq(cls, solver, bits):
+        """Build from a `GPTQ` object after `fasterquant(groupsize=g, ...)`."""
+        gs, gz = solver.group_scale, solver.group_zero          # [out, G]
+        if gs is None:
+            raise ValueError("QuantGroupLinear.from_gptq: the solver ran without groups")
+        if solver.perm is not None and not getattr(solver, "static_groups", False):
+            raise ValueError("QuantGroupLinear.from_gptq: act-order needs static groups for a g_idx-free format")
+        n_out, n_in = solver.codes.shape
+        m = cls(bits, n_in // gs.shape[1], n_in, n_out)
+        m.qweight = pack_codes(solver.codes, bits)
+        m.scales = gs.t().contiguous()
+        m.zeros = (gz * gs).t().contiguous()
+        bias = getattr(solver.layer, "bias", None)
+        m.bias = bias.detach().clone().float() if bias is not None else torch.zeros(n_out, device=gs.device)
+        return m
+
+    def forward(self, x):
+        if x.shape[-1] == x.numel():
+            outshape = list(x.shape)
+            y = self.bias.clone().float()
+            outshape[-1] = self.bias.numel()
+            dtype = x.dtype
+            xv = x if x.dtype in (torch.float16, torch.float32) else x.float()
+            quant_cuda.vecquant_matmul_grouped(xv.reshape(-1), self.qweight, y, self.scales, self.zeros,
+                                               self.bits, self.groupsize)
+            return y.to(dtype).reshape(outshape)
+        raise ValueError('Only supports a single token currently.')
+
+
 def make_quant3(module, names, name='', faster=False):
     """Replace the named Linears by empty Quant3Linear modules (reference quant.py:205-216)."""
     _make_quant(module, names, name, Quant3Linear, faster)

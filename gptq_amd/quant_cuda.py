@@ -53,3 +53,28 @@ def vecquant3matmul_faster(vec, mat, mul, scales, zeros):
 def vecquant4matmul(vec, mat, mul, scales, zeros):
     """4-bit analogue on the zeroShot/models/quant.py:185 layout; vec fp32 or fp16."""
     _run("gptq_vecquant4matmul", 4, vec, mat, mul, scales, zeros, vec.dtype if vec.dtype == torch.float16 else torch.float32)
+
+
+def vecquant_matmul_grouped(vec, mat, mul, scales, zeros, bits, groupsize):
+    """Grouped-grid mat-vec: scales / zeros are [in/groupsize, out], zeros = zero*scale."""
+    for name, t in (("vec", vec), ("mat", mat), ("mul", mul), ("scales", scales), ("zeros", zeros)):
+        _lib.require_gpu(t, name)
+    if vec.dtype not in (torch.float32, torch.float16):
+        raise TypeError("vecquant_matmul_grouped: vec must be fp32 or fp16")
+    if mat.dtype != torch.int32 or mat.dim() != 2 or not mat.is_contiguous():
+        raise TypeError("vecquant_matmul_grouped: mat must be a contiguous int32 matrix")
+    height, width = mat.shape
+    n_in = height // bits * 32
+    groups = n_in // groupsize
+    if vec.numel() != n_in or mul.numel() != width or tuple(scales.shape) != (groups, width) \
+            or tuple(zeros.shape) != (groups, width):
+        raise ValueError("vecquant_matmul_grouped: shape mismatch")
+    if mul.dtype != torch.float32 or not mul.is_contiguous():
+        raise TypeError("vecquant_matmul_grouped: mul must be contiguous fp32")
+    v = vec.reshape(-1).contiguous()
+    s = scales.to(torch.float32).contiguous()
+    z = zeros.to(torch.float32).contiguous()
+    dev = vec.device
+    with torch.cuda.device(dev):
+        _lib.call("gptq_vecquant_matmul_grouped", _lib.ptr(v), _lib.dtype_code(v), _lib.ptr(mat), _lib.ptr(mul),
+                  _lib.ptr(s), _lib.ptr(z), height, width, int(bits), int(groupsize), _lib.stream(dev))

@@ -155,6 +155,14 @@ int gptq_vecquant4matmul(const void* vec, int vec_dtype, const int32_t* mat, flo
                          const float* scales, const float* zeros, int height, int width,
                          gptq_stream_t stream);
 
+/* Grouped grids (groupsize = 128 etc.; SURVEY row f4 -- the reference cannot pack grouped models at all,
+ * Quant3Linear holds per-row scalars only, quant.py:144-145): scales / zeros are [in/groupsize, width]
+ * (row = group of ORIGINAL input columns, zeros = zero*scale), groupsize % 32 == 0:
+ *   mul[col] += sum_k (scales[k/groupsize][col]*q[k,col] - zeros[k/groupsize][col]) * vec[k]. */
+int gptq_vecquant_matmul_grouped(const void* vec, int vec_dtype, const int32_t* mat, float* mul,
+                                 const float* scales, const float* zeros, int height, int width,
+                                 int bits, int groupsize, gptq_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -576,3 +576,53 @@ def test_hessian_deferred_batches_match_immediate(G, O, hip_device):
             assert relfro(gp2.H.cpu(), H2) <= 1e-6
     finally:
         gmod.HESSIAN_DEFER = old
+
+
+# ------------------------------------------------------- f4: grouped packed format + grouped mat-vec
+@pytest.mark.parametrize("bits", [3, 4])
+@pytest.mark.parametrize("in_f,out_f,gs", [(256, 256, 128), (1024, 520, 32), (4096, 1024, 128), (768, 130, 64)])
+def test_grouped_matvec_vs_fp64_formula(G, O, bits, in_f, out_f, gs):
+    rng = np.random.default_rng(in_f + out_f + bits + gs)
+    iw = rng.integers(0, 2 ** bits, size=(in_f, out_f), dtype=np.uint32)
+    qw = (O.pack3 if bits == 3 else O.pack4)(iw)
+    ng = in_f // gs
+    scales = (rng.random((ng, out_f)) * 0.02 + 0.001).astype(np.float32)
+    zeros = (rng.integers(0, 2 ** bits, size=(ng, out_f)) * scales).astype(np.float32)
+    bias = rng.standard_normal(out_f).astype(np.float32)
+    x = rng.standard_normal(in_f).astype(np.float32)
+    grp = np.arange(in_f) // gs
+    wdeq = iw.astype(np.float64) * scales[grp].astype(np.float64) - zeros[grp].astype(np.float64)   # [in, out]
+    ref = bias.astype(np.float64) + x.astype(np.float64) @ wdeq
+    from gptq_amd import quant_cuda
+    for xt, tol in ((torch.from_numpy(x), 1e-5), (torch.from_numpy(x).half(), 1e-2)):
+        y = cuda(bias.copy())
+        quant_cuda.vecquant_matmul_grouped(xt.cuda(), cuda(qw), y, cuda(scales), cuda(zeros), bits, gs)
+        r = ref if xt.dtype == torch.float32 else bias.astype(np.float64) + xt.double().numpy() @ wdeq
+        assert np.abs(y.cpu().numpy().astype(np.float64) - r).max() <= tol * np.abs(ref).max()
+
+
+def test_grouped_module_from_gptq_matches_dense(G, hip_device):
+    """fasterquant(g128, static groups, act-order) -> QuantGroupLinear: the packed module reproduces the
+    dense quantized layer on a single token."""
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    R, C = 512, 1024
+    W = (torch.randn(R, C, device=hip_device, generator=gen) * 0.02).half()
+    lin = torch.nn.Linear(C, R, bias=True, device=hip_device, dtype=torch.float16)
+    lin.weight.data = W.clone()
+    gp = G.GPTQ(lin)
+    gp.quantizer = G.Quantizer(); gp.quantizer.configure(4, perchannel=True, sym=False, mse=False)
+    chan = (1 + torch.arange(C, device=hip_device) % 7).half()
+    for _ in range(3):
+        gp.add_batch(torch.randn(1, 2048, C, device=hip_device, generator=gen).half() * chan, None)
+    gp.fasterquant(groupsize=128, actorder=True, static_groups=True)
+    m = G.QuantGroupLinear.from_gptq(gp, 4).to(hip_device)
+    assert m.qweight.shape == (C // 8, R) and m.scales.shape == (C // 128, R)
+    x = torch.randn(1, 1, C, device=hip_device, generator=gen).half()
+    y = m(x)
+    grp = torch.arange(C, device=hip_device) // 128
+    Wq = gp.group_scale[:, grp] * (gp.codes.float() - gp.group_zero[:, grp])          # exact fp32 grid values
+    ref = (Wq.double() @ x.reshape(-1).double()) + lin.bias.double()
+    assert relfro(y.reshape(-1).cpu(), ref.cpu()) <= 2e-3       # fp16 activations / fp16 output
+    assert torch.equal(lin.weight.data, Wq.half())
+    with pytest.raises(ValueError):
+        m(torch.zeros(2, C, device=hip_device, dtype=torch.float16))
