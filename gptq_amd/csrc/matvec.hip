@@ -50,7 +50,7 @@ template <> __device__ __forceinline__ float mv_to_f32<__half>(__half v) { retur
 // groupsize == 0: one (scale, zero) per output column ([width]), applied once per workgroup.
 // groupsize  > 0: grouped grids, tables [in/groupsize, width] (row = group), applied per 32-input group:
 //                 y += s[g][col] * sum_{k in group}(q x) - z[g][col] * sum_{k in group}(x)   (SURVEY row f4).
-template <int BITS, int VW, typename TV>
+template <int BITS, int VW, typename TV, bool GROUPED>
 __global__ __launch_bounds__(256) void matvec_kernel(const TV* __restrict__ vec, const int32_t* __restrict__ mat,
                                                      float* __restrict__ mul, const float* __restrict__ scales,
                                                      const float* __restrict__ zeros, int ngroups, int width,
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void matvec_kernel(const TV* __restrict__ vec,
   for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
   if (lane == 0) xsum_s[wave] = part;
   __syncthreads();
-  if (groupsize > 0) {                                   // per-32-group sums of x for the grouped zero term
+  if (GROUPED) {                                         // per-32-group sums of x for the grouped zero term
     for (int g = tid; g < kgroups; g += 256) {
       float sx = 0.f;
 #pragma unroll
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void matvec_kernel(const TV* __restrict__ vec,
       const bool more = g + 4 < ng;
       if (more) fetch(g + 4, wb);
       float sg[VW], zg[VW];
-      if (groupsize > 0) {
+      if (GROUPED) {
         const long trow = (long)(((g0 + g) * 32) / groupsize) * width + col;
 #pragma unroll
         for (int v = 0; v < VW; ++v) { sg[v] = scales[trow + v]; zg[v] = zeros[trow + v]; acc[v] = 0.f; }
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void matvec_kernel(const TV* __restrict__ vec,
         for (int r = 0; r < BITS; ++r) wc[r] = wa[r][v];
         dot_group<BITS>(wc, xs + g * 32, acc[v]);
       }
-      if (groupsize > 0) {
+      if (GROUPED) {
         const float sx = xs32[g];
 #pragma unroll
         for (int v = 0; v < VW; ++v) tot[v] += sg[v] * acc[v] - zg[v] * sx;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void matvec_kernel(const TV* __restrict__ vec,
         for (int v = 0; v < VW; ++v) wa[r][v] = wb[r][v];
       g += 4;
     }
-    if (groupsize > 0) {
+    if (GROUPED) {
 #pragma unroll
       for (int v = 0; v < VW; ++v) acc[v] = tot[v];
     }
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void matvec_kernel(const TV* __restrict__ vec,
     const int c = blockIdx.x * 64 * VW + tid;
     if (c < width) {
       const float q = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-      if (groupsize > 0) {
+      if (GROUPED) {
         atomicAdd(&mul[c], q);
       } else {
         const float sx = xsum_s[0] + xsum_s[1] + xsum_s[2] + xsum_s[3];
@@ -171,8 +171,15 @@ static int launch_matvec(const void* vec, int vec_dtype, const int32_t* mat, flo
   int kgroups = kg_env > 0 ? std::min(kg_env, MV_KGROUPS_MAX) : 16;   // measured best on the 36864 x 9216 FC2 shape
   const dim3 grid(cdiv(width, 64 * vw), cdiv(ngroups, kgroups));
   GPTQ_CHECK_ARG(grid.y <= 65535, "%s: too many input groups", who);
-#define MV_LAUNCH(VW, TV) \
-  matvec_kernel<BITS, VW, TV><<<grid, 256, 0, s>>>(static_cast<const TV*>(vec), mat, mul, scales, zeros, ngroups, width, kgroups, groupsize)
+#define MV_LAUNCH(VW, TV)                                                                                          \
+  do {                                                                                                             \
+    if (groupsize > 0)                                                                                             \
+      matvec_kernel<BITS, VW, TV, true><<<grid, 256, 0, s>>>(static_cast<const TV*>(vec), mat, mul, scales, zeros, \
+                                                             ngroups, width, kgroups, groupsize);                  \
+    else                                                                                                           \
+      matvec_kernel<BITS, VW, TV, false><<<grid, 256, 0, s>>>(static_cast<const TV*>(vec), mat, mul, scales,       \
+                                                              zeros, ngroups, width, kgroups, groupsize);          \
+  } while (0)
   if (vec_dtype == GPTQ_F32) { if (v4) MV_LAUNCH(4, float); else MV_LAUNCH(1, float); }
   else { if (v4) MV_LAUNCH(4, __half); else MV_LAUNCH(1, __half); }
 #undef MV_LAUNCH
