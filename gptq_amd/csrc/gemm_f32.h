@@ -17,7 +17,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int GBM = 128;
 constexpr int GBN = 128;
-constexpr int GBK = 16;
+constexpr int GBK = 32;     // a stage's MFMA time (16 k-pairs x 4 MFMA x 64 cyc) must cover the global-load latency
 constexpr int GLD = 132;
 constexpr int GEMM_THREADS = 256;
 constexpr int GEMM_LDS_FLOATS = 2 * 2 * GBK * GLD;  // A,B x double buffer
@@ -63,16 +63,18 @@ __device__ __forceinline__ void load4_vec<__hip_bfloat16>(const __hip_bfloat16* 
   out[2] = __uint_as_float(v.y << 16); out[3] = __uint_as_float(v.y & 0xffff0000u);
 }
 
-// Fetch this thread's share (2 x 4 elements) of a 128 x GBK operand slab starting at k0.
-//   KC = false ("tile-contiguous", st == 1): thread -> (k = tid>>5 [+8], 4 consecutive tile rows)
-//   KC = true  ("k-contiguous",    sk == 1): thread -> (tile row = tid>>2 [+64], 4 consecutive k)
+// Fetch this thread's share (GST x 4 elements) of a 128 x GBK operand slab starting at k0.
+//   KC = false ("tile-contiguous", st == 1): thread -> (k = tid>>5 [+8h], 4 consecutive tile rows)
+//   KC = true  ("k-contiguous",    sk == 1): thread -> (tile row = tid>>3 [+32h], 4 consecutive k)
+constexpr int GST = GBK / 8;   // 4-element pieces per thread per operand stage
+
 template <typename T, bool KC>
-__device__ __forceinline__ void stage_load(const Operand<T>& o, int k0, int k_end, float r[2][4]) {
+__device__ __forceinline__ void stage_load(const Operand<T>& o, int k0, int k_end, float r[GST][4]) {
   const int tid = threadIdx.x;
   if (!KC) {
     const int m4 = (tid & 31) * 4;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < GST; ++h) {
       const int k = k0 + (tid >> 5) + 8 * h;
       const T* p = o.p + (long)m4 * o.st + (long)k * o.sk;
       if (k < k_end && o.vec && m4 + 4 <= o.rem) {
@@ -84,10 +86,10 @@ __device__ __forceinline__ void stage_load(const Operand<T>& o, int k0, int k_en
       }
     }
   } else {
-    const int k = k0 + (tid & 3) * 4;
+    const int k = k0 + (tid & 7) * 4;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int m = (tid >> 2) + 64 * h;
+    for (int h = 0; h < GST; ++h) {
+      const int m = (tid >> 3) + 32 * h;
       const T* p = o.p + (long)m * o.st + (long)k * o.sk;
       if (m < o.rem && o.vec && k + 4 <= k_end) {
         load4_vec<T>(p, r[h]);
@@ -101,20 +103,20 @@ __device__ __forceinline__ void stage_load(const Operand<T>& o, int k0, int k_en
 }
 
 template <bool KC>
-__device__ __forceinline__ void stage_store(float* S, const float r[2][4]) {
+__device__ __forceinline__ void stage_store(float* S, const float r[GST][4]) {
   const int tid = threadIdx.x;
   if (!KC) {
     const int m4 = (tid & 31) * 4;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < GST; ++h) {
       const int k = (tid >> 5) + 8 * h;
       *reinterpret_cast<float4*>(S + k * GLD + m4) = make_float4(r[h][0], r[h][1], r[h][2], r[h][3]);
     }
   } else {
-    const int k = (tid & 3) * 4;
+    const int k = (tid & 7) * 4;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int m = (tid >> 2) + 64 * h;
+    for (int h = 0; h < GST; ++h) {
+      const int m = (tid >> 3) + 32 * h;
 #pragma unroll
       for (int e = 0; e < 4; ++e) S[(k + e) * GLD + m] = r[h][e];
     }
@@ -195,7 +197,7 @@ __device__ __forceinline__ void gemm_tile(const Operand<TA>& a, const Operand<TB
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  float ra[2][4], rb[2][4];
+  float ra[GST][4], rb[GST][4];
   const int nk = (k_end - k_begin + GBK - 1) / GBK;
   if (nk > 0) {
     stage_load<TA, AKC>(a, k_begin, k_end, ra);
