@@ -237,3 +237,67 @@ def opt_eval(model, testenc, dev, args: Optional[QuantArgs] = None):
 
 def llama_eval(model, testenc, dev, args: Optional[QuantArgs] = None):
     return eval_ppl(model, testenc, dev, args)
+
+
+# ------------------------------------------------------------------------------------------------
+# Row f3: packed checkpoints and the token-by-token generation benchmark (opt.py:362-507)
+# ------------------------------------------------------------------------------------------------
+def _set_module(root, dotted, new):
+    parent = root
+    parts = dotted.split(".")
+    for p in parts[:-1]:
+        parent = getattr(parent, p)
+    setattr(parent, parts[-1], new)
+
+
+def pack_model(model, quantizers, bits, faster=False):
+    """Replace every quantized Linear by a packed module in place, like `opt_pack3` (opt.py:362-373).
+
+    Per-row grids only (what `Quant3Linear` / `Quant4Linear` can hold): run the quantization with
+    groupsize = -1.  The packing itself happens on the GPU (the reference loops over rows in numpy,
+    "TODO: perform packing on GPU", opt.py:361)."""
+    from .quant import Quant3Linear, Quant4Linear
+    cls = {3: Quant3Linear, 4: Quant4Linear}[bits]
+    layers = find_layers(model)
+    for name, q in quantizers.items():
+        lin = layers[name]
+        packed = cls(lin.in_features, lin.out_features, faster=faster)
+        packed.pack(lin, q.scale.float(), q.zero.float())
+        _set_module(model, name, packed)
+    return model
+
+
+def make_packed_skeleton(model, names, bits, faster=False):
+    """Empty packed modules for `names` (the load side of opt.py:375-402): load_state_dict then fills
+    `qweight / scales / zeros / bias`."""
+    from .quant import make_quant3, make_quant4
+    (make_quant3 if bits == 3 else make_quant4)(model, names, faster=faster)
+    return model
+
+
+@torch.no_grad()
+def benchmark(model, input_ids, dev, check=False, warmup=10):
+    """Token-by-token generation timing with the KV cache (opt.py:440-507): every Linear call is a
+    single-token packed mat-vec.  Returns (median seconds per token, PPL or None)."""
+    import time
+    import numpy as np
+    input_ids = input_ids.to(dev)
+    attention_mask = torch.ones((1, input_ids.numel()), device=dev)
+    for _ in range(warmup):
+        model(input_ids[:, 0].reshape((1, -1)), past_key_values=None, attention_mask=attention_mask[:, :1])
+    torch.cuda.synchronize()
+    past = None
+    times, tot = [], 0.0
+    loss = nn.CrossEntropyLoss()
+    for i in range(input_ids.numel()):
+        tick = time.time()
+        out = model(input_ids[:, i].reshape((1, -1)), past_key_values=past,
+                    attention_mask=attention_mask[:, :(i + 1)].reshape((1, -1)), use_cache=True)
+        torch.cuda.synchronize()
+        times.append(time.time() - tick)
+        if check and i != input_ids.numel() - 1:
+            tot += loss(out.logits[0].float(), input_ids[:, (i + 1)]).float()
+        past = out.past_key_values
+        del out
+    ppl = float(torch.exp(tot / (input_ids.numel() - 1)).item()) if check else None
+    return float(np.median(times)), ppl
