@@ -107,11 +107,12 @@ def main():
     hess_flops = 0.0
     hess_launches = 0
     big = max(mine, key=lambda i: (units[i].cols, units[i].rows)) if mine else None   # dominant launch shape
-    big_ms = [0.0]
+    flush_events = []
 
     def step(record):
         nonlocal hess_flops, hess_launches
         packed = {}
+        solvers = {}
         for i in mine:
             u = units[i]
             lin = torch.nn.Linear(u.cols, u.rows, bias=False, device=dev, dtype=torch.float16)
@@ -119,27 +120,39 @@ def main():
             g = gptq_amd.GPTQ(lin)
             g.quantizer = gptq_amd.Quantizer()
             g.quantizer.configure(BITS, perchannel=True, sym=False, mse=False)
-            X = acts[u.cols]
-            e0, e1, e2, e3 = ev(), ev(), ev(), ev()
-            e0.record()
-            for j in range(args.nsamples):                       # opt.py:184-185 -> hook -> add_batch
-                g.add_batch(X[j:j + 1], None)
-            e1.record()
+            solvers[i] = g
+        # 1. Hessians, in the order the reference's hooks fire (opt.py:184-185): per calibration sample,
+        #    every Linear of the block gets its add_batch
+        e0, e1 = ev(), ev()
+        gmod.FLUSH_EVENTS = flush_events if record else None
+        e0.record()
+        for j in range(args.nsamples):
+            for i in mine:
+                solvers[i].add_batch(acts[units[i].cols][j:j + 1], None)
+        gmod.flush_pending()
+        e1.record()
+        gmod.FLUSH_EVENTS = None
+        # 2. solve + pack, one Linear after the other (opt.py:189-214)
+        solve_ev = []
+        for i in mine:
+            g = solvers[i]
+            s0, s1, s2 = ev(), ev(), ev()
+            s0.record()
             g.fasterquant(blocksize=128, percdamp=0.01, groupsize=GROUPSIZE, actorder=False, static_groups=True)
-            e2.record()
+            s1.record()
             q = gptq_amd.pack_codes(g.codes, BITS)
-            e3.record()
+            s2.record()
             packed[i] = (q, g.group_scale, g.group_zero)
             g.free()
-            if record:
-                torch.cuda.synchronize()
-                phase_ms["hessian"] += e0.elapsed_time(e1)
-                if i == big:
-                    big_ms[0] += e0.elapsed_time(e1)
-                phase_ms["solve"] += e1.elapsed_time(e2)
-                phase_ms["pack"] += e2.elapsed_time(e3)
-                hess_flops += args.nsamples * float(SEQLEN) * u.cols * u.cols   # upper-triangle SYRK: S*C^2
-                hess_launches += -(-args.nsamples // max(1, args.hessian_defer))
+            solve_ev.append((s0, s1, s2))
+        if record:
+            torch.cuda.synchronize()
+            phase_ms["hessian"] += e0.elapsed_time(e1)
+            for s0, s1, s2 in solve_ev:
+                phase_ms["solve"] += s0.elapsed_time(s1)
+                phase_ms["pack"] += s1.elapsed_time(s2)
+            for i in mine:
+                hess_flops += args.nsamples * float(SEQLEN) * units[i].cols * units[i].cols   # upper-triangle SYRK: S*C^2
         if world > 1:
             a0, a1 = ev(), ev()
             a0.record()
@@ -193,9 +206,10 @@ def main():
         # that Linear's launch sequence / number of launches (rocprofv3 summary under profiles/ agrees).
         ub = units[big]
         per_launch = max(1, args.hessian_defer)
-        n_launch = steps * -(-args.nsamples // per_launch)
-        launch_ms = big_ms[0] / n_launch
-        flops_launch = min(per_launch, args.nsamples) * float(SEQLEN) * ub.cols * ub.cols
+        durs = [a.elapsed_time(b) for (C_, nprob, nslab, a, b) in flush_events if C_ == ub.cols and nslab == per_launch]
+        n_launch = len(durs)
+        launch_ms = sum(durs) / max(n_launch, 1)
+        flops_launch = per_launch * float(SEQLEN) * ub.cols * ub.cols
         achieved = flops_launch / (launch_ms / 1e3) / 1e12 if launch_ms > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_hessian16_pmc_defer8.json")

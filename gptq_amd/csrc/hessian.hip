@@ -211,6 +211,10 @@ __global__ __launch_bounds__(256) void hessian16_kernel(float* __restrict__ H, i
 constexpr int RING_DEFAULT = 4;
 constexpr int MAX_XLIST = 16;
 struct XList { const unsigned short* p[MAX_XLIST]; };   // up to 16 equally shaped activation slabs per launch
+constexpr int MAX_PROB = 8;
+// several independent (H, slabs) problems of identical shape in ONE launch: the Linears of a block that
+// share in_features (q,k,v,out,fc1 ...) each bring only C/128*(C/128+1)/2 tiles, too few to fill 256 CUs alone
+struct ProbGroup { float* H[MAX_PROB]; XList x[MAX_PROB]; float alpha[MAX_PROB]; float beta[MAX_PROB]; };
 constexpr int DSTAGE = 2 * HBK * 256;        // bytes per ring slot: A + B, 64 rows x 256 B each
 
 __device__ __forceinline__ void dma_stage(const unsigned short* __restrict__ Xa, const unsigned short* __restrict__ Xb,
@@ -253,13 +257,17 @@ __device__ __forceinline__ s16x8 join8(frag_t lo, frag_t hi) {
 // Workgroup = 8 waves: waves 0-3 own the MFMA quadrants, waves 4-7 only issue LDS-DMA (an LDS-DMA
 // piece costs its wave ~100-185 cycles of issue; interleaved with the MFMAs it serialised them).
 template <bool BF16, int ABLATE = 0, int RING = RING_DEFAULT>   // ABLATE (diagnostic builds only): 1 = no MFMA side, 2 = no DMA
-__global__ __launch_bounds__(512) void hessian16_dma_kernel(float* __restrict__ H, int ldh, XList xl, int nx,
-                                                            int ldx, int C, int tokens, float alpha, float beta) {
+__global__ __launch_bounds__(512) void hessian16_dma_kernel(ProbGroup pg, int tiles_per_prob, int ldh, int nx,
+                                                            int ldx, int C, int tokens) {
   // `tokens` rows per slab, `nx` slabs: the K loop walks all of them (one H update for the whole batch)
+  const int prob = blockIdx.x / tiles_per_prob;               // workgroup-uniform problem index
+  float* __restrict__ H = pg.H[prob];
+  const XList& xl = pg.x[prob];
+  const float alpha = pg.alpha[prob], beta = pg.beta[prob];
   extern __shared__ __attribute__((aligned(1024))) char ring[];          // RING x DSTAGE, the ONLY LDS object
   const int nt = C / GBM;
   int ti, tj;
-  hessian_tile_of(blockIdx.x, nt, ti, tj);
+  hessian_tile_of(blockIdx.x - prob * tiles_per_prob, nt, ti, tj);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool loader = wave >= 4;                              // wave-uniform role
@@ -365,86 +373,108 @@ __global__ __launch_bounds__(256) void symmetrize_kernel(float* __restrict__ A, 
 
 using namespace gptq;
 
-// One H update for `n_x` equally shaped slabs X[i] [tokens, C] (row-major, ldx).
-static int hessian_launch(float* H, int ldh, const void* const* xs, int n_x, int x_dtype, int ldx, int C,
-                          int tokens, float alpha, float beta, hipStream_t s) {
+// One H update per problem; every problem brings `n_x` equally shaped slabs [tokens, C] (row-major, ldx).
+struct HostProb { float* H; const void* const* xs; float alpha, beta; };
+
+static int hessian_launch(const HostProb* probs, int n_prob, int ldh, int n_x, int x_dtype, int ldx, int C,
+                          int tokens, hipStream_t s) {
   const int nt = cdiv(C, GBM);
   const int blocks = nt * (nt + 1) / 2;
   if (x_dtype == GPTQ_F16 || x_dtype == GPTQ_BF16) {
     bool aligned = (ldx % 8 == 0) && (tokens % HBK == 0) && (C % GBM == 0);
-    for (int i = 0; i < n_x; ++i) aligned = aligned && (reinterpret_cast<uintptr_t>(xs[i]) % 16 == 0);
+    for (int p = 0; p < n_prob; ++p)
+      for (int i = 0; i < n_x; ++i) aligned = aligned && (reinterpret_cast<uintptr_t>(probs[p].xs[i]) % 16 == 0);
     if (aligned) {
       static const int ring_env = [] { const char* e = getenv("GPTQ_HESS_RING"); return e ? atoi(e) : RING_DEFAULT; }();
       const size_t lds = (size_t)ring_env * DSTAGE;
       static const int ablate = [] { const char* e = getenv("GPTQ_HESS_ABLATE"); return e ? atoi(e) : 0; }();
-      for (int i0 = 0; i0 < n_x; i0 += MAX_XLIST) {
-        XList xl{};
-        const int nx = std::min(MAX_XLIST, n_x - i0);
-        for (int i = 0; i < nx; ++i) xl.p[i] = static_cast<const unsigned short*>(xs[i0 + i]);
-        const float a = i0 == 0 ? alpha : 1.f;
-#define HDMA(BF, AB)                                                                                           \
+      for (int p0 = 0; p0 < n_prob; p0 += MAX_PROB) {
+        const int np = std::min(MAX_PROB, n_prob - p0);
+        for (int i0 = 0; i0 < n_x; i0 += MAX_XLIST) {
+          const int nx = std::min(MAX_XLIST, n_x - i0);
+          ProbGroup pg{};
+          for (int p = 0; p < np; ++p) {
+            pg.H[p] = probs[p0 + p].H;
+            pg.alpha[p] = i0 == 0 ? probs[p0 + p].alpha : 1.f;
+            pg.beta[p] = probs[p0 + p].beta;
+            for (int i = 0; i < nx; ++i) pg.x[p].p[i] = static_cast<const unsigned short*>(probs[p0 + p].xs[i0 + i]);
+          }
+#define HDMA(BF, AB, RG)                                                                                       \
   do {                                                                                                         \
-    GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_dma_kernel<BF, AB>),           \
+    GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_dma_kernel<BF, AB, RG>),       \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
-    hessian16_dma_kernel<BF, AB><<<blocks, 512, lds, s>>>(H, ldh, xl, nx, ldx, C, tokens, a, beta);            \
+    hessian16_dma_kernel<BF, AB, RG><<<np * blocks, 512, lds, s>>>(pg, blocks, ldh, nx, ldx, C, tokens);       \
   } while (0)
-        if (x_dtype == GPTQ_F16 && ring_env == 2) {
-          GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_dma_kernel<false, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          hessian16_dma_kernel<false, 0, 2><<<blocks, 512, lds, s>>>(H, ldh, xl, nx, ldx, C, tokens, a, beta);
-        } else if (x_dtype == GPTQ_F16 && ring_env == 3) {
-          GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_dma_kernel<false, 0, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          hessian16_dma_kernel<false, 0, 3><<<blocks, 512, lds, s>>>(H, ldh, xl, nx, ldx, C, tokens, a, beta);
-        } else if (x_dtype == GPTQ_BF16) HDMA(true, 0);
-        else if (ablate == 1) HDMA(false, 1);
-        else if (ablate == 2) HDMA(false, 2);
-        else HDMA(false, 0);
+          if (x_dtype == GPTQ_BF16) HDMA(true, 0, RING_DEFAULT);
+          else if (ring_env == 3) HDMA(false, 0, 3);
+          else if (ablate == 1) HDMA(false, 1, RING_DEFAULT);
+          else if (ablate == 2) HDMA(false, 2, RING_DEFAULT);
+          else HDMA(false, 0, RING_DEFAULT);
 #undef HDMA
+        }
       }
       GPTQ_CHECK_LAUNCH("hessian16_dma_kernel");
       return GPTQ_OK;
     }
   }
-  for (int i = 0; i < n_x; ++i) {
-    const float a = i == 0 ? alpha : 1.f;
-    switch (x_dtype) {
-      case GPTQ_F32: {
-        const float* x = static_cast<const float*>(xs[i]);
-        hessian_kernel<float><<<blocks, GEMM_THREADS, 0, s>>>(H, ldh, x, ldx, C, tokens, a, beta, vec_ok(x, ldx));
-        break;
-      }
-      case GPTQ_F16:
-      case GPTQ_BF16: {
-        const unsigned short* x = static_cast<const unsigned short*>(xs[i]);
-        const bool vec = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (ldx % 8 == 0);
-        const size_t lds = sizeof(unsigned short) * 4 * HTILE;
-        if (x_dtype == GPTQ_F16) {
-          GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          hessian16_kernel<false><<<blocks, 256, lds, s>>>(H, ldh, x, ldx, C, tokens, a, beta, vec);
-        } else {
-          GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          hessian16_kernel<true><<<blocks, 256, lds, s>>>(H, ldh, x, ldx, C, tokens, a, beta, vec);
+  for (int p = 0; p < n_prob; ++p) {
+    float* H = probs[p].H;
+    for (int i = 0; i < n_x; ++i) {
+      const float a = i == 0 ? probs[p].alpha : 1.f;
+      const float beta = probs[p].beta;
+      switch (x_dtype) {
+        case GPTQ_F32: {
+          const float* x = static_cast<const float*>(probs[p].xs[i]);
+          hessian_kernel<float><<<blocks, GEMM_THREADS, 0, s>>>(H, ldh, x, ldx, C, tokens, a, beta, vec_ok(x, ldx));
+          break;
         }
-        break;
+        case GPTQ_F16:
+        case GPTQ_BF16: {
+          const unsigned short* x = static_cast<const unsigned short*>(probs[p].xs[i]);
+          const bool vec = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (ldx % 8 == 0);
+          const size_t lds = sizeof(unsigned short) * 4 * HTILE;
+          if (x_dtype == GPTQ_F16) {
+            GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hessian16_kernel<false><<<blocks, 256, lds, s>>>(H, ldh, x, ldx, C, tokens, a, beta, vec);
+          } else {
+            GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hessian16_kernel<true><<<blocks, 256, lds, s>>>(H, ldh, x, ldx, C, tokens, a, beta, vec);
+          }
+          break;
+        }
+        default:
+          GPTQ_CHECK_ARG(false, "gptq_hessian_accum: unknown dtype %d", x_dtype);
       }
-      default:
-        GPTQ_CHECK_ARG(false, "gptq_hessian_accum: unknown dtype %d", x_dtype);
     }
   }
   GPTQ_CHECK_LAUNCH("hessian_kernel");
   return GPTQ_OK;
 }
 
+extern "C" int gptq_hessian_accum_group(int n_prob, float* const* H, int ldh, const void* const* X, int n_x,
+                                        int x_dtype, int ldx, int C, int tokens_each,
+                                        const int* nsamples_before, int batch_total, gptq_stream_t stream) {
+  GPTQ_CHECK_ARG(n_prob > 0 && n_prob <= 64 && H && X && nsamples_before && n_x > 0, "gptq_hessian_accum_group: bad arguments");
+  GPTQ_CHECK_ARG(C > 0 && tokens_each > 0 && batch_total > 0, "gptq_hessian_accum_group: bad sizes");
+  GPTQ_CHECK_ARG(ldh >= C && ldx >= C, "gptq_hessian_accum_group: leading dimension smaller than C");
+  HostProb probs[64];
+  for (int p = 0; p < n_prob; ++p) {
+    GPTQ_CHECK_ARG(H[p] != nullptr && nsamples_before[p] >= 0, "gptq_hessian_accum_group: bad problem %d", p);
+    for (int i = 0; i < n_x; ++i) GPTQ_CHECK_ARG(X[(long)p * n_x + i] != nullptr, "gptq_hessian_accum_group: null slab");
+    const int n_after = nsamples_before[p] + batch_total;
+    probs[p] = HostProb{H[p], X + (long)p * n_x,
+                        (float)((double)nsamples_before[p] / (double)n_after),   // gptq.py:59
+                        (float)(2.0 / (double)n_after)};                         // gptq.py:62 squared
+  }
+  return hessian_launch(probs, n_prob, ldh, n_x, x_dtype, ldx, C, tokens_each, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int gptq_hessian_accum_multi(float* H, int ldh, const void* const* X, int n_x, int x_dtype, int ldx,
                                         int C, int tokens_each, int nsamples_before, int batch_total,
                                         gptq_stream_t stream) {
-  GPTQ_CHECK_ARG(H && X && n_x > 0, "gptq_hessian_accum_multi: null pointer");
-  for (int i = 0; i < n_x; ++i) GPTQ_CHECK_ARG(X[i] != nullptr, "gptq_hessian_accum_multi: null slab %d", i);
-  GPTQ_CHECK_ARG(C > 0 && tokens_each > 0 && batch_total > 0 && nsamples_before >= 0, "gptq_hessian_accum_multi: bad sizes");
-  GPTQ_CHECK_ARG(ldh >= C && ldx >= C, "gptq_hessian_accum_multi: leading dimension smaller than C");
-  const int n_after = nsamples_before + batch_total;
-  const float alpha = (float)((double)nsamples_before / (double)n_after);   // gptq.py:59
-  const float beta = (float)(2.0 / (double)n_after);                        // gptq.py:62 squared
-  return hessian_launch(H, ldh, X, n_x, x_dtype, ldx, C, tokens_each, alpha, beta, static_cast<hipStream_t>(stream));
+  float* Hs[1] = {H};
+  const int nb[1] = {nsamples_before};
+  return gptq_hessian_accum_group(1, Hs, ldh, X, n_x, x_dtype, ldx, C, tokens_each, nb, batch_total, stream);
 }
 
 extern "C" int gptq_hessian_accum(float* H, int ldh, const void* X, int x_dtype, int ldx, int C,

@@ -35,6 +35,45 @@ TRACK_INPUT_MEAN = False
 HESSIAN_DEFER = 1
 
 
+_DIRTY = {}     # id -> GPTQ objects holding deferred hook inputs
+FLUSH_EVENTS = None   # set to a list to collect (C, n_problems, n_slabs, start_event, end_event) per Hessian launch
+
+
+def flush_pending():
+    """Fold every deferred hook input into its H.  Objects whose pending inputs have the same shape
+    (the Linears of one block that share in_features) go out as ONE grouped launch
+    (gptq_hessian_accum_group): alone, each brings too few 128x128 tiles to fill the 256 CUs."""
+    import ctypes
+    global _DIRTY
+    objs = [o for o in _DIRTY.values() if o._pending and o._H is not None]
+    _DIRTY = {}
+    groups = {}
+    for o in objs:
+        x0 = o._pending[0][0]
+        key = (o.dev, o.columns, x0.shape[0], x0.dtype, x0.stride(0), len(o._pending),
+               sum(b for _, b in o._pending), o._H.stride(0))
+        groups.setdefault(key, []).append(o)
+    for (dev, C, tokens, dtype, ldx, n_x, batch, ldh), members in groups.items():
+        for i in range(0, len(members), 64):
+            chunk = members[i:i + 64]
+            Hs = (ctypes.c_void_p * len(chunk))(*[o._H.data_ptr() for o in chunk])
+            Xs = (ctypes.c_void_p * (len(chunk) * n_x))(*[x.data_ptr() for o in chunk for x, _ in o._pending])
+            nb = (ctypes.c_int * len(chunk))(*[int(o._applied) for o in chunk])
+            with torch.cuda.device(dev):
+                if FLUSH_EVENTS is not None:
+                    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ev0.record()
+                _lib.call("gptq_hessian_accum_group", len(chunk), Hs, ldh, Xs, n_x, _lib._DTYPES[dtype], ldx, C,
+                          tokens, nb, int(batch), _lib.stream(dev))
+                if FLUSH_EVENTS is not None:
+                    ev1.record()
+                    FLUSH_EVENTS.append((C, len(chunk), n_x, ev0, ev1))
+            for o in chunk:
+                o._applied += batch
+                o._pending = []
+                o._lower_stale = True
+
+
 class GPTQ:
 
     def __init__(self, layer):
@@ -56,20 +95,7 @@ class GPTQ:
 
     # -- H stays reachable as a full symmetric tensor; mirrored lazily -------------
     def _flush(self):
-        if not self._pending:
-            return
-        import ctypes
-        xs = [x for x, _ in self._pending]
-        batch = sum(b for _, b in self._pending)
-        arr = (ctypes.c_void_p * len(xs))(*[x.data_ptr() for x in xs])
-        x0 = xs[0]
-        with torch.cuda.device(self.dev):
-            _lib.call("gptq_hessian_accum_multi", _lib.ptr(self._H), self._H.stride(0), arr, len(xs),
-                      _lib.dtype_code(x0), x0.stride(0), self.columns, x0.shape[0], int(self._applied), int(batch),
-                      _lib.stream(self.dev))
-        self._applied += batch
-        self._pending = []
-        self._lower_stale = True
+        flush_pending()
 
     @property
     def H(self):
@@ -83,6 +109,7 @@ class GPTQ:
     @H.setter
     def H(self, value):
         self._pending = []
+        _DIRTY.pop(id(self), None)
         self._H = value
         self._lower_stale = False
 
@@ -113,11 +140,12 @@ class GPTQ:
             raise ValueError(f"add_batch: input has {x.shape[1]} features, layer expects {self.columns}")
         if self._pending and (self._pending[0][0].shape != x.shape or self._pending[0][0].dtype != x.dtype
                               or self._pending[0][0].stride(0) != x.stride(0)):
-            self._flush()
+            flush_pending()
         self._pending.append((x, batch))
+        _DIRTY[id(self)] = self
         self.nsamples += batch
         if len(self._pending) >= max(1, int(HESSIAN_DEFER)):
-            self._flush()
+            flush_pending()       # everything deferred so far, grouped by shape
         if TRACK_INPUT_MEAN:   # fork addition (gptq.py:63), unused by the default branch
             self.input = x.mean(0, dtype=torch.float32) * math.sqrt(2 / self.nsamples)
 
@@ -206,6 +234,7 @@ class GPTQ:
             self.out1 = None
         self._H = None
         self._pending = []
+        _DIRTY.pop(id(self), None)
         self.Hinv = None
         self.codes = None
         self.Losses = None

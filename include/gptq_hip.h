@@ -56,6 +56,14 @@ int gptq_hessian_accum_multi(float* H, int ldh, const void* const* X, int n_x, i
                              int C, int tokens_each, int nsamples_before, int batch_total,
                              gptq_stream_t stream);
 
+/* Several independent problems of identical shape in one launch (the Linears of a transformer block
+ * that share in_features: q/k/v/out/fc1 ... each bring too few 128x128 tiles to fill 256 CUs alone).
+ * H: host array of n_prob device pointers; X: host array of n_prob*n_x device pointers (problem-major);
+ * nsamples_before: host array [n_prob]. */
+int gptq_hessian_accum_group(int n_prob, float* const* H, int ldh, const void* const* X, int n_x,
+                             int x_dtype, int ldx, int C, int tokens_each, const int* nsamples_before,
+                             int batch_total, gptq_stream_t stream);
+
 /* Mirror the upper triangle of A [n, n] into the lower triangle. */
 int gptq_symmetrize(float* A, int lda, int n, gptq_stream_t stream);
 

@@ -626,3 +626,36 @@ def test_grouped_module_from_gptq_matches_dense(G, hip_device):
     assert torch.equal(lin.weight.data, Wq.half())
     with pytest.raises(ValueError):
         m(torch.zeros(2, C, device=hip_device, dtype=torch.float16))
+
+
+def test_hessian_grouped_problems_single_launch(G, O, hip_device):
+    """Several GPTQ objects with equally shaped pending inputs are flushed by ONE grouped launch
+    (gptq_hessian_accum_group); each must still get exactly its own Hessian."""
+    import gptq_amd.gptq as gmod
+    gen = torch.Generator().manual_seed(31)
+    C, S, n = 256, 128, 5
+    old = gmod.HESSIAN_DEFER
+    try:
+        gmod.HESSIAN_DEFER = 4
+        solvers = [G.GPTQ(make_linear(torch.zeros(4, C, device=hip_device))) for _ in range(3)]
+        other = G.GPTQ(make_linear(torch.zeros(4, 384, device=hip_device)))      # different in_features: own launch
+        refs = [torch.zeros(C, C) for _ in range(3)]
+        counts = [0, 0, 0]
+        ref_o, cnt_o = torch.zeros(384, 384), 0
+        gmod.FLUSH_EVENTS = []
+        for j in range(n):
+            for k, g in enumerate(solvers):
+                x = (torch.randn(1, S, C, generator=gen) * (1 + k + torch.arange(C) % 5)).half()
+                g.add_batch(x.cuda(), None)
+                counts[k] = O.hessian_add_batch(refs[k], counts[k], x)
+            xo = torch.randn(1, S, 384, generator=gen).half()
+            other.add_batch(xo.cuda(), None)
+            cnt_o = O.hessian_add_batch(ref_o, cnt_o, xo)
+        launches = list(gmod.FLUSH_EVENTS)
+        for k, g in enumerate(solvers):
+            assert relfro(g.H.cpu(), refs[k]) <= 1e-6
+        assert relfro(other.H.cpu(), ref_o) <= 1e-6
+        assert any(nprob == 3 and c == C for (c, nprob, nslab, _, _) in launches)   # the three went out together
+    finally:
+        gmod.HESSIAN_DEFER = old
+        gmod.FLUSH_EVENTS = None
