@@ -141,11 +141,13 @@ class GPTQ:
         if self._pending and (self._pending[0][0].shape != x.shape or self._pending[0][0].dtype != x.dtype
                               or self._pending[0][0].stride(0) != x.stride(0)):
             flush_pending()
+        if len(self._pending) >= max(1, int(HESSIAN_DEFER)):
+            # this object is about to exceed the batch: its lock-step peers (the other Linears hooked in
+            # the same forward passes) hold exactly as many inputs, so everything goes out grouped by shape
+            flush_pending()
         self._pending.append((x, batch))
         _DIRTY[id(self)] = self
         self.nsamples += batch
-        if len(self._pending) >= max(1, int(HESSIAN_DEFER)):
-            flush_pending()       # everything deferred so far, grouped by shape
         if TRACK_INPUT_MEAN:   # fork addition (gptq.py:63), unused by the default branch
             self.input = x.mean(0, dtype=torch.float32) * math.sqrt(2 / self.nsamples)
 
