@@ -7,6 +7,8 @@
 //   => H + damp I = R R^T with R = J L J upper triangular, hence (H + damp I)^-1 = R^-T R^-1
 //   U = R^-1 = J L^-1 J            (L^-1 by recursive doubling: log2(C/128) levels of batched GEMMs)
 // All arithmetic is IEEE fp32 (no TF32/bf16), like gptq.py:18-19.
+#include <stdlib.h>
+
 #include "gemm_f32.h"
 
 namespace gptq {
@@ -171,6 +173,214 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// v2 of the diagonal block kernel: hierarchical, 32-wide sub-blocks.
+//   factorization, for s = 0..3:  (A1) wave 0 factors the 32x32 diagonal sub-block in REGISTERS (lane =
+//   row, v_readlane broadcasts, no barrier inside);  (A2) the sub-panel below is solved by per-row forward
+//   substitution (thread = row, L_D broadcast from LDS);  (A3) the remaining sub-blocks get their rank-32
+//   update on the matrix cores (one 32x32 tile per wave).  3 barriers per 32 columns instead of 1 per column.
+//   inverse:  (B1) the four 32x32 diagonal inverses by column-per-lane substitution (4 waves in
+//   parallel);  (B2/B3) two levels of recursive doubling on the matrix cores, the intermediate product of
+//   level 1 staying in accumulator registers (it is consumed as the next MFMA's B operand directly).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lane_bcast(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+// acc(32x32, MFMA C layout) += sign * A * B  over K = 32, operands addressed as A(i,k) = Ap[i*lda + k],
+// B(k,j) = Bp[j*ldb + k]  (i.e. B given as its transpose, row-major), all in LDS.
+__device__ __forceinline__ void lds_mfma32(f32x16& acc, const float* Ap, int lda, const float* Bp, int ldb,
+                                           float sign, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) {
+    const float a = sign * Ap[r * lda + 2 * kk + h];
+    const float b = Bp[r * ldb + 2 * kk + h];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  }
+}
+// same with B(k,j) = Bp[k*ldb + j] (B row-major)
+__device__ __forceinline__ void lds_mfma32_bn(f32x16& acc, const float* Ap, int lda, const float* Bp, int ldb,
+                                              float sign, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) {
+    const float a = sign * Ap[r * lda + 2 * kk + h];
+    const float b = Bp[(2 * kk + h) * ldb + r];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  }
+}
+__device__ __forceinline__ void acc_load(f32x16& acc, const float* T, int ld, int lane) {
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = T[((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * ld + (lane & 31)];
+}
+__device__ __forceinline__ void acc_store(const f32x16& acc, float* T, int ld, int lane) {
+#pragma unroll
+  for (int e = 0; e < 16; ++e) T[((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * ld + (lane & 31)] = acc[e];
+}
+
+__global__ __launch_bounds__(512) void potrf_inv_diag_v2_kernel(float* __restrict__ A, float* __restrict__ Linv,
+                                                                int Cp, int kb, int32_t* __restrict__ info) {
+  constexpr int LD = NB + 1;            // 129: row-strided accesses (lane = row) are conflict-free
+  constexpr int LDD = 36;               // 32x32 scratch blocks, 16-byte aligned rows
+  extern __shared__ __attribute__((aligned(16))) float dsm[];
+  float* S = dsm;                       // [128][129]  A_kk -> L_kk (lower)
+  float* Xs = S + NB * LD;              // [128][129]  L_kk^-1 (lower, zero above)
+  float* Ld = Xs + NB * LD;             // [32][36]    current diagonal sub-block L_D (row-major)
+  float* Tt = Ld + 32 * LDD;            // [64][65]    level-2 intermediate T = L_CA * X_A
+  float* rd = Tt + 64 * 65;             // [128]       1 / l_jj
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* Ak = A + (long)kb * NB * Cp + (long)kb * NB;
+
+  for (int idx = tid; idx < NB * NB; idx += 512) {
+    const int i = idx >> 7, k = idx & 127;
+    S[i * LD + k] = (k <= i) ? Ak[(long)i * Cp + k] : Ak[(long)k * Cp + i];   // symmetric fill (A3 updates full tiles)
+    Xs[i * LD + k] = 0.f;
+  }
+  __syncthreads();
+
+  // ------------------------------- factorization -------------------------------
+#pragma unroll 1
+  for (int s = 0; s < 4; ++s) {
+    const int o = 32 * s;
+    if (wave == 0) {                                            // (A1) 32x32 in registers, lane = row
+      const int row = lane & 31;
+      float a[32];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) a[k] = S[(o + row) * LD + o + k];
+#pragma unroll
+      for (int j = 0; j < 32; ++j) {
+        const float ajj = lane_bcast(a[j], j);
+        const float d = sqrtf(ajj);
+        const float inv = 1.f / d;
+        if (lane == 0) {
+          rd[o + j] = inv;
+          if (!(ajj > 0.f) && info) atomicCAS(info, 0, kb * NB + o + j + 1);
+        }
+        const float lj = (row == j) ? d : a[j] * inv;
+        a[j] = lj;
+#pragma unroll
+        for (int k = j + 1; k < 32; ++k) a[k] -= lj * lane_bcast(lj, k);
+      }
+      if (lane < 32) {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+          const float v = (k <= row) ? a[k] : 0.f;
+          S[(o + row) * LD + o + k] = v;
+          Ld[row * LDD + k] = v;
+        }
+      }
+    }
+    __syncthreads();
+    const int below = NB - o - 32;                              // rows under the diagonal sub-block
+    if (tid < below) {                                          // (A2) x * L_D^T = p, one row per thread
+      const int i = o + 32 + tid;
+      float x[32];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) x[k] = S[i * LD + o + k];
+#pragma unroll
+      for (int j = 0; j < 32; ++j) {
+        float acc = x[j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) acc -= x[k] * Ld[j * LDD + k];
+        x[j] = acc * rd[o + j];
+      }
+#pragma unroll
+      for (int k = 0; k < 32; ++k) S[i * LD + o + k] = x[k];
+    }
+    __syncthreads();
+    {                                                           // (A3) S[I,K] -= P_I P_K^T, s < K <= I
+      const int nb_rem = 3 - s;                                 // sub-blocks left: indices s+1 .. 3
+      const int ntile = nb_rem * (nb_rem + 1) / 2;
+      if (wave < ntile) {
+        int t = wave, K = 0;
+        while (t >= nb_rem - K) { t -= nb_rem - K; ++K; }
+        const int I = K + t;                                    // relative indices, I >= K
+        const int ri = 32 * (s + 1 + I), rk = 32 * (s + 1 + K);
+        f32x16 acc;
+        acc_load(acc, S + ri * LD + rk, LD, lane);
+        lds_mfma32(acc, S + ri * LD + o, LD, S + rk * LD + o, LD, -1.f, lane);
+        acc_store(acc, S + ri * LD + rk, LD, lane);
+      }
+    }
+    __syncthreads();
+  }
+  // L_kk back to A (kept for inspection)
+  for (int idx = tid; idx < NB * NB; idx += 512) {
+    const int i = idx >> 7, k = idx & 127;
+    if (k <= i) Ak[(long)i * Cp + k] = S[i * LD + k];
+  }
+
+  // ---------------------------------- inverse ----------------------------------
+  if (wave < 4) {                                               // (B1) X_D = L_D^-1, lane = column
+    const int o = 32 * wave;
+    const int c = lane & 31;
+    float x[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+      float acc = (r == c) ? 1.f : 0.f;
+#pragma unroll
+      for (int k = 0; k < r; ++k) acc -= S[(o + r) * LD + o + k] * x[k];     // L[r][k]: same address for all lanes
+      x[r] = (r >= c) ? acc * rd[o + r] : 0.f;
+    }
+    if (lane < 32) {
+#pragma unroll
+      for (int r = 0; r < 32; ++r) Xs[(o + r) * LD + o + c] = x[r];
+    }
+  }
+  __syncthreads();
+  if (wave < 2) {                                               // (B2) X[2p+1, 2p] = -X_C * (L_CA * X_A), 32x32 blocks
+    const int a0 = 64 * wave, c0 = a0 + 32;
+    f32x16 T;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) T[e] = 0.f;
+    lds_mfma32_bn(T, S + c0 * LD + a0, LD, Xs + a0 * LD + a0, LD, 1.f, lane);   // T = L_CA * X_A
+    // X = -X_C * T with T straight from the accumulator registers: MFMA step t takes, in lane half h,
+    // the k index  r(t, h) = (t & 3) + 8 * (t >> 2) + 4 * h  -- the row of T that register t holds
+    f32x16 X;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) X[e] = 0.f;
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int k = (t & 3) + 8 * (t >> 2) + 4 * h;
+      const float av = -Xs[(c0 + r) * LD + c0 + k];
+      X = __builtin_amdgcn_mfma_f32_32x32x2f32(av, T[t], X, 0, 0, 0);
+    }
+    acc_store(X, Xs + c0 * LD + a0, LD, lane);
+  }
+  __syncthreads();
+  if (wave < 4) {                                               // (B3a) T[64x64] = L[64:128, 0:64] * X[0:64, 0:64]
+    const int I = wave >> 1, J = wave & 1;
+    f32x16 T;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) T[e] = 0.f;
+#pragma unroll
+    for (int K = 0; K < 2; ++K)
+      lds_mfma32_bn(T, S + (64 + 32 * I) * LD + 32 * K, LD, Xs + (32 * K) * LD + 32 * J, LD, 1.f, lane);
+    acc_store(T, Tt + (32 * I) * 65 + 32 * J, 65, lane);
+  }
+  __syncthreads();
+  if (wave < 4) {                                               // (B3b) X[64:128, 0:64] = -X[64:128, 64:128] * T
+    const int I = wave >> 1, J = wave & 1;
+    f32x16 X;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) X[e] = 0.f;
+#pragma unroll
+    for (int K = 0; K < 2; ++K)
+      lds_mfma32_bn(X, Xs + (64 + 32 * I) * LD + 64 + 32 * K, LD, Tt + (32 * K) * 65 + 32 * J, 65, -1.f, lane);
+    acc_store(X, Xs + (64 + 32 * I) * LD + 32 * J, LD, lane);
+  }
+  __syncthreads();
+  float* Xk = Linv + (long)kb * NB * Cp + (long)kb * NB;
+  for (int idx = tid; idx < NB * NB; idx += 512) {
+    const int i = idx >> 7, k = idx & 127;
+    Xk[(long)i * Cp + k] = (k <= i) ? Xs[i * LD + k] : 0.f;
+  }
+}
+constexpr size_t POTRF_V2_LDS = sizeof(float) * (2 * NB * (NB + 1) + 32 * 36 + 64 * 65 + NB);
+
 // Panel:  P <- P * inv(L_kk)^T  for the block column kb below the diagonal (rows (kb+1)*128 ...).
 __global__ __launch_bounds__(GEMM_THREADS) void panel_kernel(float* __restrict__ A,
                                                              const float* __restrict__ Linv, int Cp, int kb) {
@@ -281,8 +491,13 @@ extern "C" int gptq_hinv_upper(float* H, int ldh, int C, float percdamp, const i
   // helper stream underneath the (serial, latency-bound) factorization.
   SideCtx* sc = (lookahead_mask() & 1) ? side_ctx() : nullptr;
   bool side_busy = false;
+  static const int potrf_v2 = [] { const char* e = getenv("GPTQ_POTRF_V2"); return e ? atoi(e) : 1; }();
+  if (potrf_v2)
+    GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_inv_diag_v2_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_V2_LDS));
   for (int kb = 0; kb < nblk; ++kb) {
-    potrf_inv_diag_kernel<<<1, 512, 0, s>>>(A, Linv, Cp, kb, info);
+    if (potrf_v2) potrf_inv_diag_v2_kernel<<<1, 512, POTRF_V2_LDS, s>>>(A, Linv, Cp, kb, info);
+    else potrf_inv_diag_kernel<<<1, 512, 0, s>>>(A, Linv, Cp, kb, info);
     const int nrem = nblk - kb - 1;
     if (nrem <= 0) break;
     if (side_busy) GPTQ_CHECK_HIP(hipStreamWaitEvent(s, sc->side_done, 0));   // SYRK of panel kb-1 finished
