@@ -220,7 +220,7 @@ __device__ __forceinline__ void acc_store(const f32x16& acc, float* T, int ld, i
 }
 
 __global__ __launch_bounds__(512) void potrf_inv_diag_v2_kernel(float* __restrict__ A, float* __restrict__ Linv,
-                                                                int Cp, int kb, int32_t* __restrict__ info) {
+                                                                int Cp, int kb, int32_t* __restrict__ info, int ablate) {
   constexpr int LD = NB + 1;            // 129: row-strided accesses (lane = row) are conflict-free
   constexpr int LDD = 36;               // 32x32 scratch blocks, 16-byte aligned rows
   extern __shared__ __attribute__((aligned(16))) float dsm[];
@@ -233,18 +233,24 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_v2_kernel(float* __restric
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* Ak = A + (long)kb * NB * Cp + (long)kb * NB;
 
-  for (int idx = tid; idx < NB * NB; idx += 512) {
+  for (int idx = tid; idx < NB * NB; idx += 512) {              // coalesced: lower triangle only
     const int i = idx >> 7, k = idx & 127;
-    S[i * LD + k] = (k <= i) ? Ak[(long)i * Cp + k] : Ak[(long)k * Cp + i];   // symmetric fill (A3 updates full tiles)
+    if (k <= i) S[i * LD + k] = Ak[(long)i * Cp + k];
     Xs[i * LD + k] = 0.f;
   }
   __syncthreads();
+  for (int idx = tid; idx < NB * NB; idx += 512) {              // mirror inside LDS (A3 updates full diagonal tiles)
+    const int i = idx >> 7, k = idx & 127;
+    if (k > i) S[i * LD + k] = S[k * LD + i];
+  }
+  __syncthreads();
+  const int abl = ablate;   // diagnostic: bit 0 skip A1, bit 1 skip A2, bit 2 skip A3, bit 3 skip inverse
 
   // ------------------------------- factorization -------------------------------
 #pragma unroll 1
   for (int s = 0; s < 4; ++s) {
     const int o = 32 * s;
-    if (wave == 0) {                                            // (A1) 32x32 in registers, lane = row
+    if (wave == 0 && !(abl & 1)) {                              // (A1) 32x32 in registers, lane = row
       const int row = lane & 31;
       float a[32];
 #pragma unroll
@@ -274,7 +280,7 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_v2_kernel(float* __restric
     }
     __syncthreads();
     const int below = NB - o - 32;                              // rows under the diagonal sub-block
-    if (tid < below) {                                          // (A2) x * L_D^T = p, one row per thread
+    if (tid < below && !(abl & 2)) {                            // (A2) x * L_D^T = p, one row per thread
       const int i = o + 32 + tid;
       float x[32];
 #pragma unroll
@@ -293,7 +299,7 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_v2_kernel(float* __restric
     {                                                           // (A3) S[I,K] -= P_I P_K^T, s < K <= I
       const int nb_rem = 3 - s;                                 // sub-blocks left: indices s+1 .. 3
       const int ntile = nb_rem * (nb_rem + 1) / 2;
-      if (wave < ntile) {
+      if (wave < ntile && !(abl & 4)) {
         int t = wave, K = 0;
         while (t >= nb_rem - K) { t -= nb_rem - K; ++K; }
         const int I = K + t;                                    // relative indices, I >= K
@@ -313,6 +319,7 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_v2_kernel(float* __restric
   }
 
   // ---------------------------------- inverse ----------------------------------
+  if (abl & 8) return;
   if (wave < 4) {                                               // (B1) X_D = L_D^-1, lane = column
     const int o = 32 * wave;
     const int c = lane & 31;
@@ -492,11 +499,12 @@ extern "C" int gptq_hinv_upper(float* H, int ldh, int C, float percdamp, const i
   SideCtx* sc = (lookahead_mask() & 1) ? side_ctx() : nullptr;
   bool side_busy = false;
   static const int potrf_v2 = [] { const char* e = getenv("GPTQ_POTRF_V2"); return e ? atoi(e) : 1; }();
+  static const int potrf_abl = [] { const char* e = getenv("GPTQ_POTRF_ABLATE"); return e ? atoi(e) : 0; }();
   if (potrf_v2)
     GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_inv_diag_v2_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_V2_LDS));
   for (int kb = 0; kb < nblk; ++kb) {
-    if (potrf_v2) potrf_inv_diag_v2_kernel<<<1, 512, POTRF_V2_LDS, s>>>(A, Linv, Cp, kb, info);
+    if (potrf_v2) potrf_inv_diag_v2_kernel<<<1, 512, POTRF_V2_LDS, s>>>(A, Linv, Cp, kb, info, potrf_abl);
     else potrf_inv_diag_kernel<<<1, 512, 0, s>>>(A, Linv, Cp, kb, info);
     const int nrem = nblk - kb - 1;
     if (nrem <= 0) break;

@@ -102,15 +102,24 @@ __device__ __forceinline__ void stage_load(const Operand<T>& o, int k0, int k_en
   }
 }
 
+// LDS image stride per operand kind.  Tile-contiguous operands are written with 16-byte stores and need
+// a stride that is a multiple of 4 (132).  K-contiguous operands are TRANSPOSED on the way in (4 scalar
+// stores per loaded float4); with stride 132 those stores were 4-way bank conflicted (measured: 33-50 % of
+// all LDS cycles of the chain GEMMs); an odd stride (129) makes them at most 2-way, which is free for
+// ds_write_b32, while fragment reads (32 consecutive floats of one k row) are conflict free for any stride.
+template <bool KC>
+struct LdsStride { static constexpr int v = KC ? 129 : GLD; };
+
 template <bool KC>
 __device__ __forceinline__ void stage_store(float* S, const float r[GST][4]) {
+  constexpr int LDS_ = LdsStride<KC>::v;
   const int tid = threadIdx.x;
   if (!KC) {
     const int m4 = (tid & 31) * 4;
 #pragma unroll
     for (int h = 0; h < GST; ++h) {
       const int k = (tid >> 5) + 8 * h;
-      *reinterpret_cast<float4*>(S + k * GLD + m4) = make_float4(r[h][0], r[h][1], r[h][2], r[h][3]);
+      *reinterpret_cast<float4*>(S + k * LDS_ + m4) = make_float4(r[h][0], r[h][1], r[h][2], r[h][3]);
     }
   } else {
     const int k = (tid & 7) * 4;
@@ -118,7 +127,7 @@ __device__ __forceinline__ void stage_store(float* S, const float r[GST][4]) {
     for (int h = 0; h < GST; ++h) {
       const int m = (tid >> 3) + 32 * h;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) S[(k + e) * GLD + m] = r[h][e];
+      for (int e = 0; e < 4; ++e) S[(k + e) * LDS_ + m] = r[h][e];
     }
   }
 }
@@ -213,13 +222,14 @@ __device__ __forceinline__ void gemm_tile(const Operand<TA>& a, const Operand<TB
       stage_load<TA, AKC>(a, k_begin + (kt + 1) * GBK, k_end, ra);
       stage_load<TB, BKC>(b, k_begin + (kt + 1) * GBK, k_end, rb);
     }
+    constexpr int LDA = LdsStride<AKC>::v, LDB = LdsStride<BKC>::v;
     const float* Ac = As + cur * GBK * GLD + wm * 64 + (lane & 31);
     const float* Bc = Bs + cur * GBK * GLD + wn * 64 + (lane & 31);
 #pragma unroll
     for (int kk = 0; kk < GBK; kk += 2) {
       const int k = kk + (lane >> 5);
-      const float a0 = Ac[k * GLD], a1 = Ac[k * GLD + 32];
-      const float b0 = Bc[k * GLD], b1 = Bc[k * GLD + 32];
+      const float a0 = Ac[k * LDA], a1 = Ac[k * LDA + 32];
+      const float b0 = Bc[k * LDB], b1 = Bc[k * LDB + 32];
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
