@@ -35,6 +35,7 @@ _SIGNATURES = {
                                    _p, _p, _p, _z, _p]),
     "gptq_pack_weights": (C.c_int, [_p, _i, _i, _i, _i, _p, _p, _i, _p, _p]),
     "gptq_pack_codes": (C.c_int, [_p, _i, _i, _i, _i, _p, _p]),
+    "gptq_dequant_packed": (C.c_int, [_p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _p]),
     "gptq_vecquant3matmul": (C.c_int, [_p, _i, _p, _p, _p, _p, _i, _i, _p]),
     "gptq_vecquant4matmul": (C.c_int, [_p, _i, _p, _p, _p, _p, _i, _i, _p]),
     "gptq_vecquant_matmul_grouped": (C.c_int, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p]),

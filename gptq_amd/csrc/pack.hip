@@ -100,6 +100,37 @@ static int launch_pack(const T* src, int ld, int n_out, int n_in, const float* s
   return GPTQ_OK;
 }
 
+// Packed -> dense:  W[o][i] = scale[g][o] * (code - zero[g][o]),  g = i / groupsize  (tables [G, out], `zero`
+// the INTEGER zero point, so the arithmetic is the solver's own `scale * (q - zero)`, quant.py:10, and every
+// rank of a sharded run reconstructs bit-identical weights).  One thread per (32-input group, output).
+template <typename T, int BITS>
+__global__ __launch_bounds__(256) void dequant_kernel(const int32_t* __restrict__ qweight,
+                                                      const float* __restrict__ scale, const float* __restrict__ zero,
+                                                      int n_out, int n_in, int groupsize, T* __restrict__ W, int ldw) {
+  const int o = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int gi = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (o >= n_out || (gi + 1) * 32 > n_in) return;
+  uint32_t w[BITS];
+#pragma unroll
+  for (int k = 0; k < BITS; ++k) w[k] = (uint32_t)qweight[((long)gi * BITS + k) * n_out + o];
+  const long trow = (long)((gi * 32) / groupsize) * n_out + o;
+  const float s = scale[trow], z = zero[trow];
+  T* dst = W + (long)o * ldw + gi * 32;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    uint32_t v;
+    if (BITS == 3) {
+      const int bit = 3 * j, word = bit >> 5, off = bit & 31;
+      v = (off <= 29) ? (w[word] >> off) & 7u : __builtin_amdgcn_alignbit(w[(word + 1) % BITS], w[word], off) & 7u;
+    } else {
+      v = (w[j >> 3] >> (4 * (j & 7))) & 15u;
+    }
+    const float q = s * ((float)v - z);
+    if constexpr (sizeof(T) == 4) dst[j] = q;
+    else dst[j] = static_cast<T>(q);
+  }
+}
+
 }  // namespace gptq
 
 using namespace gptq;
@@ -136,4 +167,24 @@ extern "C" int gptq_pack_codes(const uint8_t* codes, int ldc, int out_features, 
   GPTQ_CHECK_ARG(ldc >= in_features, "gptq_pack_codes: leading dimension too small");
   return launch_pack<float, 1>(reinterpret_cast<const float*>(codes), ldc, out_features, in_features,
                                nullptr, nullptr, bits, qweight, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int gptq_dequant_packed(const int32_t* qweight, const float* scale, const float* zero, int out_features,
+                                   int in_features, int bits, int groupsize, void* weight, int w_dtype, int ldw,
+                                   gptq_stream_t stream) {
+  GPTQ_CHECK_ARG(qweight && scale && zero && weight, "gptq_dequant_packed: null pointer");
+  if (int rc = check_pack_shape("gptq_dequant_packed", out_features, in_features, bits)) return rc;
+  if (groupsize <= 0) groupsize = in_features;
+  GPTQ_CHECK_ARG(groupsize % 32 == 0 && in_features % groupsize == 0 && ldw >= in_features,
+                 "gptq_dequant_packed: groupsize must be a multiple of 32 dividing in_features");
+  const dim3 grid(cdiv(out_features, 64), cdiv(in_features / 32, 4));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define DQ(T, B) dequant_kernel<T, B><<<grid, 256, 0, s>>>(qweight, scale, zero, out_features, in_features, groupsize, static_cast<T*>(weight), ldw)
+  if (w_dtype == GPTQ_F32) { if (bits == 3) DQ(float, 3); else DQ(float, 4); }
+  else if (w_dtype == GPTQ_F16) { if (bits == 3) DQ(__half, 3); else DQ(__half, 4); }
+  else if (w_dtype == GPTQ_BF16) { if (bits == 3) DQ(__hip_bfloat16, 3); else DQ(__hip_bfloat16, 4); }
+  else GPTQ_CHECK_ARG(false, "gptq_dequant_packed: unknown dtype %d", w_dtype);
+#undef DQ
+  GPTQ_CHECK_LAUNCH("dequant_kernel");
+  return GPTQ_OK;
 }

@@ -125,6 +125,21 @@ def pack_codes(codes, bits):
     return qweight
 
 
+def dequant_packed(qweight, scale, zero, bits, groupsize, dtype=torch.float16):
+    """int32 [in/32*bits, out] + grids [G, out] (`zero` = integer zero point) -> dense [out, in] weights,
+    computed as scale * (code - zero) like the solver itself (quant.py:10)."""
+    dev = _dev_of(qweight)
+    n_out = qweight.shape[1]
+    n_in = qweight.shape[0] // bits * 32
+    W = torch.empty((n_out, n_in), dtype=dtype, device=dev)
+    s = scale.to(torch.float32).contiguous()
+    z = zero.to(torch.float32).contiguous()
+    with torch.cuda.device(dev):
+        _lib.call("gptq_dequant_packed", _lib.ptr(qweight.contiguous()), _lib.ptr(s), _lib.ptr(z), n_out, n_in, int(bits),
+                  int(groupsize), _lib.ptr(W), _lib.dtype_code(W), W.stride(0), _lib.stream(dev))
+    return W
+
+
 class _QuantLinearBase(nn.Module):
     bits = 0
 

@@ -112,9 +112,31 @@ def _run_layer(layer, x, kwargs):
     return out.reshape(x.shape)
 
 
+def _packed_tables(solver, groupsize):
+    """(scale, zero) tables [out, G] of a finished solver: per group, or per row (G = 1)."""
+    if groupsize > 0:
+        if solver.perm is not None and not solver.static_groups:
+            raise NotImplementedError("sharded runs need static groups with act-order (no g_idx in the packed format)")
+        return solver.group_scale, solver.group_zero
+    return solver.quantizer.scale.reshape(-1, 1).float(), solver.quantizer.zero.reshape(-1, 1).float()
+
+
 @torch.no_grad()
-def quantize_sequential(model, dataloader, dev, args: QuantArgs) -> Dict[str, Quantizer]:
-    """GPTQ every Linear of every decoder block; returns {full_name: quantizer} like the reference."""
+def quantize_sequential(model, dataloader, dev, args: QuantArgs, group=None) -> Dict[str, Quantizer]:
+    """GPTQ every Linear of every decoder block; returns {full_name: quantizer} like the reference.
+
+    With torch.distributed initialised (one process per GPU) the Linears hooked in the same forward
+    pass are dealt to the ranks by cost: every rank runs the (replicated) block
+    forward, but accumulates Hessians and solves only for ITS Linears; one all-gather of the packed
+    weights + grids per group, then every rank rebuilds all Linears from the packed form, so all ranks
+    hold bit-identical weights for the next forward pass."""
+    import torch.distributed as dist
+    from . import parallel as par
+    from .quant import dequant_packed, pack_codes
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    if world > 1 and args.wbits not in (3, 4):
+        raise NotImplementedError("sharded runs exchange packed weights: wbits must be 3 or 4")
     from . import gptq as _gptq_mod
     _gptq_mod.HESSIAN_DEFER = max(1, int(args.hessian_defer))
     use_cache = model.config.use_cache
@@ -134,6 +156,12 @@ def quantize_sequential(model, dataloader, dev, args: QuantArgs) -> Dict[str, Qu
             groups = [list(full.keys())]
         for names in groups:
             subset = {n: full[n] for n in names}
+            units, assignment = None, None
+            if world > 1:
+                units = [par.Unit(n, subset[n].out_features, subset[n].in_features) for n in names]
+                costs = [par.unit_cost(u, args.nsamples, model.seqlen, args.blocksize) for u in units]
+                assignment = par.assign_units(costs, world)
+                subset = {names[k]: full[names[k]] for k in assignment[rank]}
             solvers = {}
             for name, lin in subset.items():
                 solvers[name] = GPTQ(lin)
@@ -157,7 +185,27 @@ def quantize_sequential(model, dataloader, dev, args: QuantArgs) -> Dict[str, Qu
                 key = f"{fam['prefix']}.{i}.{name}"
                 quantizers[key] = solvers[name].quantizer
                 records.append(dict(name=key, error=solvers[name].error))
-                solvers[name].free()
+                if world == 1:
+                    solvers[name].free()
+            if world > 1:
+                local = {}
+                for k in assignment[rank]:
+                    sv = solvers[names[k]]
+                    st, zt = _packed_tables(sv, args.groupsize)
+                    local[k] = (pack_codes(sv.codes, args.wbits), st.contiguous(), zt.contiguous())
+                    sv.free()
+                everything = par.allgather_packed(local, units, assignment, args.wbits, args.groupsize, group=group)
+                for k, name in enumerate(names):
+                    qw, st, zt = everything[k]
+                    lin = full[name]
+                    lin.weight.data = dequant_packed(qw.to(dev), st.t().contiguous().to(dev), zt.t().contiguous().to(dev),
+                                                     args.wbits, args.groupsize, dtype=lin.weight.dtype)
+                    key = f"{fam['prefix']}.{i}.{name}"
+                    if key not in quantizers:                   # grids of Linears other ranks solved
+                        q = Quantizer()
+                        q.configure(args.wbits, perchannel=True, sym=args.sym, mse=False)
+                        q.scale, q.zero = st[:, -1:].clone(), zt[:, -1:].clone()
+                        quantizers[key] = q
         for j in range(args.nsamples):                        # opt.py:216-217: next block sees quantized outputs
             outs[j] = _run_layer(layer, inps[j], kwargs)
         layers[i] = layer.cpu()

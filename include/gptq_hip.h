@@ -148,6 +148,13 @@ int gptq_pack_weights(const void* weight, int w_dtype, int ldw, int out_features
 int gptq_pack_codes(const uint8_t* codes, int ldc, int out_features, int in_features, int bits,
                     int32_t* qweight, gptq_stream_t stream);
 
+/* Packed -> dense weights: W[o][i] = scale[g][o] * (code - zero[g][o]), g = i / groupsize, tables
+ * [in/groupsize, out] with `zero` the INTEGER zero point (quant.py:10 arithmetic); groupsize <= 0 means one
+ * group.  Used to rebuild the Linears other ranks quantized and packed checkpoints. */
+int gptq_dequant_packed(const int32_t* qweight, const float* scale, const float* zero, int out_features,
+                        int in_features, int bits, int groupsize, void* weight, int w_dtype, int ldw,
+                        gptq_stream_t stream);
+
 /* ---------------------------------------------------------------------------
  * Packed dequant mat-vec -- replaces quant_cuda.vecquant3matmul /
  * vecquant3matmul_faster (quant_cuda.cpp:15-29, quant_cuda_kernel.cu:31-244):
