@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--nsamples", type=int, default=128, help="calibration samples per step (reference default 128)")
     ap.add_argument("--hessian-defer", type=int, default=8,
                     help="hook inputs folded into H per launch (gptq_amd.gptq.HESSIAN_DEFER; 1 = per call like the reference)")
+    ap.add_argument("--serial-solve", action="store_true", help="solve the Linears one by one instead of on concurrent streams")
+    ap.add_argument("--solve-streams", type=int, default=0, help="concurrent solves (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=128, help="calibration samples in the CPU baseline sample")
     return ap.parse_args()
@@ -132,19 +134,24 @@ def main():
         gmod.flush_pending()
         e1.record()
         gmod.FLUSH_EVENTS = None
-        # 2. solve + pack, one Linear after the other (opt.py:189-214)
-        solve_ev = []
+        # 2. solve + pack for every Linear of the block (opt.py:189-214); the solves are independent and go out
+        #    on separate streams (gptq_amd.fasterquant_many), --serial-solve restores the one-by-one loop
+        s0, s1, s2 = ev(), ev(), ev()
+        s0.record()
+        if args.serial_solve:
+            for i in mine:
+                solvers[i].fasterquant(blocksize=128, percdamp=0.01, groupsize=GROUPSIZE, actorder=False,
+                                       static_groups=True)
+        else:
+            gptq_amd.fasterquant_many([solvers[i] for i in mine], blocksize=128, percdamp=0.01, groupsize=GROUPSIZE,
+                                      actorder=False, static_groups=True, max_concurrent=args.solve_streams or None)
+        s1.record()
         for i in mine:
             g = solvers[i]
-            s0, s1, s2 = ev(), ev(), ev()
-            s0.record()
-            g.fasterquant(blocksize=128, percdamp=0.01, groupsize=GROUPSIZE, actorder=False, static_groups=True)
-            s1.record()
-            q = gptq_amd.pack_codes(g.codes, BITS)
-            s2.record()
-            packed[i] = (q, g.group_scale, g.group_zero)
+            packed[i] = (gptq_amd.pack_codes(g.codes, BITS), g.group_scale, g.group_zero)
             g.free()
-            solve_ev.append((s0, s1, s2))
+        s2.record()
+        solve_ev = [(s0, s1, s2)]
         if record:
             torch.cuda.synchronize()
             phase_ms["hessian"] += e0.elapsed_time(e1)
@@ -212,11 +219,12 @@ def main():
         flops_launch = per_launch * float(SEQLEN) * ub.cols * ub.cols
         achieved = flops_launch / (launch_ms / 1e3) / 1e12 if launch_ms > 0 else 0.0
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_hessian16_pmc_defer8.json")
+        pmc = os.path.join(ROOT, "profiles", "r01_hessian16_big_pmc.json")   # tools/pmc_traffic.py, same launch shape
         if os.path.exists(pmc) and ub.cols == 8192 and per_launch == 8:
             traffic = json.load(open(pmc))["hbm_bytes_per_launch"]      # FETCH_SIZE x2 (gfx950) + WRITE_SIZE
         out["roofline"] = {
-            "kernel": "hessian16_dma_kernel<f16> (v_mfma_f32_32x32x16_f16 SYRK, upper-triangle tiles, fp32 accumulate)",
+            "kernel": "hessian16_big_kernel<f16> + hessian16_big_fixup (v_mfma_f32_32x32x16_f16 SYRK, 256x256 upper-triangle "
+                      "tiles, K-split last round, fp32 accumulate)",
             "launch_shape": f"C={ub.cols}, {per_launch} samples x {SEQLEN} tokens per launch", "bound": "mfma",
             "achieved": round(achieved, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4), "traffic": traffic,

@@ -496,7 +496,7 @@ extern "C" int gptq_hinv_upper(float* H, int ldh, int C, float percdamp, const i
   // Look-ahead: the diagonal factorization of panel kb+1 only needs tile (kb+1, kb+1), so that tile is
   // updated on the caller's stream right after panel kb and the rest of the trailing SYRK runs on a
   // helper stream underneath the (serial, latency-bound) factorization.
-  SideCtx* sc = (lookahead_mask() & 1) ? side_ctx() : nullptr;
+  SideCtx* sc = (lookahead_mask() & 1) ? side_ctx(s) : nullptr;
   bool side_busy = false;
   static const int potrf_v2 = [] { const char* e = getenv("GPTQ_POTRF_V2"); return e ? atoi(e) : 1; }();
   static const int potrf_abl = [] { const char* e = getenv("GPTQ_POTRF_ABLATE"); return e ? atoi(e) : 0; }();

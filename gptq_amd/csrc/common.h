@@ -39,14 +39,16 @@ void set_error(const char* fmt, ...);
     }                                                               \
   } while (0)
 
-// Per-device helper stream + events for look-ahead overlap inside one library call (created once,
+// Per-(device, caller stream) helper stream + events for look-ahead overlap inside one library call (created once,
 // reused; the caller's stream stays the only externally visible ordering point).
 struct SideCtx {
   hipStream_t stream = nullptr;
   hipEvent_t main_done = nullptr;   // recorded on the caller's stream
   hipEvent_t side_done = nullptr;   // recorded on the side stream
 };
-SideCtx* side_ctx();                // nullptr if it cannot be created (callers then run serially)
+SideCtx* side_ctx(hipStream_t main);   // nullptr if it cannot be created (callers then run serially)
+// Library-owned device scratch per (device, caller stream), grown on demand and kept (nullptr on failure).
+void* scratch_buffer(hipStream_t main, size_t bytes);
 int lookahead_mask();               // bit 0: factorization chain, bit 1: column loop (env GPTQ_LOOKAHEAD)
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -3,27 +3,48 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <map>
 #include <mutex>
+#include <utility>
 
 #include "common.h"
 
 namespace gptq {
-SideCtx* side_ctx() {
+SideCtx* side_ctx(hipStream_t main) {
+  // one helper stream per (device, caller stream): solves enqueued on different streams stay independent
   static std::mutex mu;
-  static SideCtx ctx[64];
-  static bool ready[64] = {};
+  static std::map<std::pair<int, hipStream_t>, SideCtx> table;
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   std::lock_guard<std::mutex> lock(mu);
-  if (!ready[dev]) {
-    SideCtx c;
-    if (hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&c.main_done, hipEventDisableTiming) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&c.side_done, hipEventDisableTiming) != hipSuccess) return nullptr;
-    ctx[dev] = c;
-    ready[dev] = true;
+  const auto key = std::make_pair(dev, main);
+  auto it = table.find(key);
+  if (it != table.end()) return &it->second;
+  if (table.size() >= 256) return nullptr;                      // callers then run serially
+  SideCtx c;
+  if (hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  if (hipEventCreateWithFlags(&c.main_done, hipEventDisableTiming) != hipSuccess) return nullptr;
+  if (hipEventCreateWithFlags(&c.side_done, hipEventDisableTiming) != hipSuccess) return nullptr;
+  return &table.emplace(key, c).first->second;
+}
+
+void* scratch_buffer(hipStream_t main, size_t bytes) {
+  struct Buf { void* p = nullptr; size_t n = 0; };
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, Buf> table;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  Buf& b = table[std::make_pair(dev, main)];
+  if (b.n >= bytes) return b.p;
+  if (b.p) {
+    // work enqueued earlier on this stream may still use the old block
+    if (hipStreamSynchronize(main) != hipSuccess || hipFree(b.p) != hipSuccess) return nullptr;
+    b = Buf{};
   }
-  return &ctx[dev];
+  if (hipMalloc(&b.p, bytes) != hipSuccess) { b = Buf{}; return nullptr; }
+  b.n = bytes;
+  return b.p;
 }
 
 int lookahead_mask() {

@@ -494,7 +494,7 @@ extern "C" int gptq_fasterquant(float* W, int ldw, float* H, int ldh, int R, int
   // Look-ahead: after block b only the NEXT block's columns are updated on the caller's stream; the
   // rest of the trailing GEMM runs on a helper stream underneath the column loop of block b+1 (which
   // is latency-bound and leaves most CUs idle).  Err1 is double buffered for that.
-  SideCtx* sc = (lookahead_mask() & 2) ? side_ctx() : nullptr;
+  SideCtx* sc = (lookahead_mask() & 2) ? side_ctx(s) : nullptr;
   bool side_busy = false;
   int blk = 0;
   for (int i1 = 0; i1 < C; i1 += blocksize, ++blk) {              // gptq.py:191

@@ -350,6 +350,310 @@ __global__ __launch_bounds__(512) void hessian16_dma_kernel(ProbGroup pg, int ti
   tile_epilogue(acc, Epilogue{Ht, ldh, 1, EPI_AXPBY, ti == tj ? TRI_UPPER : TRI_ALL, alpha, beta}, GBM, GBN, wm, wn, lane);
 }
 
+// ---------------------------------------------------------------------------------------------
+// 256 x 256 tiles for C % 256 == 0 (every hidden size of the OPT / LLaMA families).  Why: a CU pulls
+// operands from L2 into LDS at ~40 B/clk (fill_rate microbench; 64 B/clk is the vector-L1 ceiling), and a
+// 128 x 128 tile needs 64 B/clk to keep the f16 MFMAs busy (8 KB per 16-token k-step = 4 MFMAs x 32 clk per
+// SIMD), so the kernel above tops out near 30 % of the matrix peak however deep its ring is.  A 256 x 256
+// tile needs 32 B/clk.  8 waves as 2 (M) x 4 (N), 128 x 64 outputs each (128 accumulator registers, two waves
+// per SIMD so one wave's LDS-DMA issue / fragment waits sit under the other's MFMAs); every wave issues its
+// own 4 LDS-DMA pieces per 32-token stage; ring of 4 stages x 32 KB.  A stage is four [32 tokens][128
+// channels] images (A lo/hi, B lo/hi) in the same XOR-swizzled layout as above, so the fragment addressing
+// is unchanged: 12 transposed reads feed 8 MFMAs per 16-token k-step.
+// The K order per output element is the same as in the 128 x 128 kernel, so both produce identical bits.
+// ---------------------------------------------------------------------------------------------
+constexpr int BT = 256;                       // tile edge
+constexpr int BBK = 32;                       // tokens per stage
+constexpr int BHALF = BBK * 256;              // bytes of one [32 tokens][128 channels] image
+constexpr int BSTAGE = 4 * BHALF;             // A lo, A hi, B lo, B hi
+constexpr int BRING_DEFAULT = 4;
+
+#define BTR_A(F, KK)                                         \
+  do {                                                       \
+    TR_READ(F[0], a0, (KK) * 4096);  TR_READ(F[1], a0, (KK) * 4096 + 1024);   \
+    TR_READ(F[2], a1, (KK) * 4096);  TR_READ(F[3], a1, (KK) * 4096 + 1024);   \
+    TR_READ(F[4], a2, (KK) * 4096);  TR_READ(F[5], a2, (KK) * 4096 + 1024);   \
+    TR_READ(F[6], a3, (KK) * 4096);  TR_READ(F[7], a3, (KK) * 4096 + 1024);   \
+  } while (0)
+#define BTR_B(F, KK)                                         \
+  do {                                                       \
+    TR_READ(F[8], b0, (KK) * 4096);  TR_READ(F[9], b0, (KK) * 4096 + 1024);   \
+    TR_READ(F[10], b1, (KK) * 4096); TR_READ(F[11], b1, (KK) * 4096 + 1024);  \
+  } while (0)
+// The twelve reads of a k-step in four groups of three (one group per MFMA gap: three transposed reads beside
+// an MFMA are free, MI355X_MICROARCH.md "Issued between MFMAs")
+#define BTR_G0(F, KK) do { TR_READ(F[0], a0, (KK) * 4096); TR_READ(F[1], a0, (KK) * 4096 + 1024); TR_READ(F[2], a1, (KK) * 4096); } while (0)
+#define BTR_G1(F, KK) do { TR_READ(F[3], a1, (KK) * 4096 + 1024); TR_READ(F[4], a2, (KK) * 4096); TR_READ(F[5], a2, (KK) * 4096 + 1024); } while (0)
+#define BTR_G2(F, KK) do { TR_READ(F[6], a3, (KK) * 4096); TR_READ(F[7], a3, (KK) * 4096 + 1024); TR_READ(F[8], b0, (KK) * 4096); } while (0)
+#define BTR_G3(F, KK) do { TR_READ(F[9], b0, (KK) * 4096 + 1024); TR_READ(F[10], b1, (KK) * 4096); TR_READ(F[11], b1, (KK) * 4096 + 1024); } while (0)
+#define BSB __builtin_amdgcn_sched_barrier(0)
+// Eight MFMAs on the complete fragment set FC; the reads of the NEXT k-step (set FN, k-step KKN of the stage that
+// a0..b1 address) ride in the first four MFMA gaps, this wave's four LDS-DMA pieces (PIECES) in the last four.
+#define BSTEP(FC, FN, KKN, PIECES)                                                  \
+  do {                                                                              \
+    const s16x8 fb0 = join8(FC[8], FC[9]), fb1 = join8(FC[10], FC[11]);             \
+    s16x8 fa = join8(FC[0], FC[1]);                                                 \
+    BSB;                                                                            \
+    if (ABL != 1) acc[0][0] = mfma16<BF16>(fa, fb0, acc[0][0]);                     \
+    BSB; if (ABL != 1) BTR_G0(FN, KKN); BSB;                                        \
+    if (ABL != 1) acc[0][1] = mfma16<BF16>(fa, fb1, acc[0][1]);                     \
+    BSB; if (ABL != 1) BTR_G1(FN, KKN); BSB;                                        \
+    fa = join8(FC[2], FC[3]);                                                       \
+    if (ABL != 1) acc[1][0] = mfma16<BF16>(fa, fb0, acc[1][0]);                     \
+    BSB; if (ABL != 1) BTR_G2(FN, KKN); BSB;                                        \
+    if (ABL != 1) acc[1][1] = mfma16<BF16>(fa, fb1, acc[1][1]);                     \
+    BSB; if (ABL != 1) BTR_G3(FN, KKN); BSB;                                        \
+    fa = join8(FC[4], FC[5]);                                                       \
+    if (ABL != 1) acc[2][0] = mfma16<BF16>(fa, fb0, acc[2][0]);                     \
+    BSB; if (PIECES) piece(0); BSB;                                                 \
+    if (ABL != 1) acc[2][1] = mfma16<BF16>(fa, fb1, acc[2][1]);                     \
+    BSB; if (PIECES) piece(1); BSB;                                                 \
+    fa = join8(FC[6], FC[7]);                                                       \
+    if (ABL != 1) acc[3][0] = mfma16<BF16>(fa, fb0, acc[3][0]);                     \
+    BSB; if (PIECES) piece(2); BSB;                                                 \
+    if (ABL != 1) acc[3][1] = mfma16<BF16>(fa, fb1, acc[3][1]);                     \
+    BSB; if (PIECES) piece(3); BSB;                                                 \
+  } while (0)
+
+// Work decomposition (data-parallel rounds + a split last round).  T tiles over P CUs leave the last round
+// partly empty (fc2 of OPT-1.3b: 528 tiles = 2.06 rounds on 256 CUs, paid as 3).  The first floor(T/P)*P tiles
+// are whole-K workgroups with the direct epilogue; the `left_tiles` remaining ones are cut along K: `workers`
+// workgroups take equal contiguous runs of the (tile, stage) sequence -- at most two segments each, since a run is
+// never longer than one tile's K -- write their fp32 partial tiles to a workspace, and hessian16_big_fixup
+// adds the partials of a tile in run order (fixed order: results do not depend on timing) and applies the epilogue.
+struct BigPlan {
+  int tiles_per_prob;   // 256 x 256 upper-triangle tiles of one problem
+  int dp_tiles;         // tiles done whole by workgroups [0, dp_tiles)
+  int left_tiles;       // tiles cut along K
+  int workers;          // workgroups [dp_tiles, dp_tiles + workers)
+  int chunk;            // stages per worker run
+  float* ws;            // workers x 2 partial tiles of 256 x 256 fp32
+};
+constexpr int BTILE_FLOATS = BT * BT;
+
+// register (t, u, e) of wave `wave`, lane `lane`  <->  element of the 256 x 256 tile (C/D map of the 32x32 MFMA:
+// col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)); partial tiles are stored in register
+// order ([wave][t][u][e][lane]: every store instruction writes 256 contiguous bytes)
+__device__ __forceinline__ long big_part_index(int wave, int t, int u, int e, int lane) {
+  return ((((long)wave * 4 + t) * 2 + u) * 16 + e) * 64 + lane;
+}
+
+// H = alpha H + beta v for the 32-row block pair t of this wave: all old values are loaded before any store
+// (a per-element read-modify-write compiles into serialized round trips)
+__device__ __forceinline__ void big_epilogue_rows(float* __restrict__ H, int ldh, int ti, int tj, int wm, int wn,
+                                                  int lane, int t, const float (&v)[2][16], float alpha, float beta) {
+  const bool diag = ti == tj;
+  const int row0 = ti * BT + wm * 128 + 4 * (lane >> 5) + t * 32;
+  const int col0 = tj * BT + wn * 64 + (lane & 31);
+  float old[2][16];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = row0 + (e & 3) + 8 * (e >> 2), col = col0 + u * 32;
+      old[u][e] = (!diag || row <= col) ? H[(long)row * ldh + col] : 0.f;
+    }
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = row0 + (e & 3) + 8 * (e >> 2), col = col0 + u * 32;
+      const float out = alpha * old[u][e] + beta * v[u][e];              // contraction off: fl(fl(a*h) + fl(b*v))
+      if (!diag || row <= col) H[(long)row * ldh + col] = out;
+    }
+}
+
+// ABL (diagnostic builds only): 1 = no fragment reads / MFMAs, 2 = no LDS-DMA.
+template <bool BF16, int BRING = BRING_DEFAULT, int ABL = 0>
+__global__ __launch_bounds__(512) void hessian16_big_kernel(ProbGroup pg, BigPlan plan, int ldh, int nx,
+                                                            int ldx, int C, int tokens) {
+  extern __shared__ __attribute__((aligned(1024))) char ring[];          // BRING x BSTAGE, the ONLY LDS object
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int spk = tokens / BBK;                               // stages per slab
+  const int nk_all = spk * nx;                                // stages of a whole tile
+
+  // transposed-read byte offsets inside a stage (row 8h + q of a 16-token k-step); the XOR swizzle acts on
+  // bits 2-3 of the chunk index, i.e. on the 32-channel block number: block t of this lane sits at (t ^ q)
+  const int h = lane >> 5, g = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
+  const int lane_off = (8 * h + q) * 256 + 32 * g + 16 * (p >> 1) + 8 * (p & 1);
+  const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)ring);
+  const unsigned oa = lds0 + wm * BHALF + lane_off;
+  const unsigned ob = lds0 + (2 + (wn >> 1)) * BHALF + lane_off;
+  const unsigned oa0 = oa + 64 * (0 ^ q), oa1 = oa + 64 * (1 ^ q), oa2 = oa + 64 * (2 ^ q), oa3 = oa + 64 * (3 ^ q);
+  const unsigned ob0 = ob + 64 * ((2 * (wn & 1)) ^ q), ob1 = ob + 64 * ((2 * (wn & 1) + 1) ^ q);
+  // LDS-DMA: wave w fills image (w >> 1), token rows 16 (w & 1) + 4 u + (lane >> 4), u = 0..3
+  const int img = wave >> 1;
+  const int rl = lane >> 4;
+  const int chunk16 = (lane & 15) ^ (rl << 2);                // logical 16-byte chunk this lane fetches
+  const int dma_dst = img * BHALF + (16 * (wave & 1)) * 256;  // wave-uniform; the DMA adds lane * 16
+
+  // this workgroup's segments: (tile, stages [s0, s1), partial slot or -1 for the direct epilogue)
+  const int bid = blockIdx.x;
+  int run_begin = 0, run_end = 0;
+  const bool whole = bid < plan.dp_tiles;
+  if (!whole) {
+    run_begin = (bid - plan.dp_tiles) * plan.chunk;
+    run_end = min(run_begin + plan.chunk, plan.left_tiles * nk_all);
+  }
+  for (int seg = 0; seg < 2; ++seg) {
+    int tile, s0, s1;
+    if (whole) {
+      if (seg == 1) break;
+      tile = bid; s0 = 0; s1 = nk_all;
+    } else {
+      const int l = run_begin / nk_all + seg;
+      s0 = seg == 0 ? run_begin - l * nk_all : 0;
+      s1 = min(run_end - l * nk_all, nk_all);
+      if (s1 <= s0) break;
+      tile = plan.dp_tiles + l;
+    }
+    const int prob = tile / plan.tiles_per_prob;
+    const XList& xl = pg.x[prob];
+    int ti, tj;
+    hessian_tile_of(tile - prob * plan.tiles_per_prob, C / BT, ti, tj);
+    const int nk = s1 - s0;
+
+    const long gcol = (img < 2 ? (long)ti * BT : (long)tj * BT) + (img & 1) * 128;
+    const long lane_goff = (long)(16 * (wave & 1) + rl) * ldx + gcol + 8 * chunk16;
+    // issue cursor: stages are issued strictly in order, so the source pointer of the NEXT stage is advanced
+    // right after each issue (the slab-pointer load then has a whole stage to return)
+    int is_slab = s0 / spk, is_in = s0 - is_slab * spk, is_st = 0;
+    const unsigned short* src = xl.p[is_slab] + lane_goff + (long)is_in * BBK * ldx;
+    auto piece = [&](int u) {
+      if (ABL == 2) return;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (long)(4 * u) * ldx),
+                                       (__attribute__((address_space(3))) void*)(ring + (is_st % BRING) * BSTAGE + dma_dst + u * 1024),
+                                       16, 0, 0);
+    };
+    // Stages past the end of the segment re-load its last stage (3 redundant stage loads per segment), so that
+    // the loop below is branch-free: always BRING - 1 stages in flight, one constant `vmcnt`.
+    auto advance = [&]() {
+      ++is_st;
+      if (is_st < nk) {
+        if (++is_in == spk) {
+          is_in = 0;
+          ++is_slab;
+          src = xl.p[is_slab] + lane_goff;
+        } else {
+          src += (long)BBK * ldx;
+        }
+      }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.f;
+
+#pragma unroll
+    for (int st = 0; st < BRING - 1; ++st) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) piece(u);
+      advance();
+    }
+    if (BRING == 5) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                               // stage 0 landed for every wave
+#pragma unroll
+    for (int u = 0; u < 4; ++u) piece(u);
+    advance();
+
+    // NOTE for maintainers: the compiler does not know these reads are asynchronous.  Nothing may touch their
+    // destination registers before the covering s_waitcnt -- tools/check_async_lds.py (run by the CPU tests)
+    // verifies that on the generated ISA.
+    frag_t f0[12], f1[12];
+    {
+      const unsigned a0 = oa0, a1 = oa1, a2 = oa2, a3 = oa3, b0 = ob0, b1 = ob1;
+      if (ABL != 1) { BTR_A(f0, 0); BTR_B(f0, 0); }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int kt = 0; kt < nk; ++kt) {
+      {
+        // k-step 0 of stage kt (f0, complete) under the reads of its k-step 1
+        const unsigned sb = (kt % BRING) * BSTAGE;
+        const unsigned a0 = oa0 + sb, a1 = oa1 + sb, a2 = oa2 + sb, a3 = oa3 + sb, b0 = ob0 + sb, b1 = ob1 + sb;
+        BSTEP(f0, f1, 1, false);
+      }
+      // own pieces of stage kt+1 landed (stages kt+2 .. kt+BRING-1 stay in flight); all reads of stage kt done
+      if (BRING == 5) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                             // stage kt+1 visible; slot of stage kt is free
+      {
+        // k-step 1 of stage kt (f1, complete) under the first reads of stage kt+1 (after the last stage: harmless
+        // dummy reads) and this wave's four LDS-DMA pieces of stage kt + BRING, into the slot stage kt just left
+        const unsigned sn = ((kt + 1) % BRING) * BSTAGE;
+        const unsigned a0 = oa0 + sn, a1 = oa1 + sn, a2 = oa2 + sn, a3 = oa3 + sn, b0 = ob0 + sn, b1 = ob1 + sn;
+        BSTEP(f1, f0, 0, true);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      advance();
+    }
+    // the dummy reads and the redundant tail stages must be gone before registers / ring slots are reused
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+
+    if (whole) {
+      float* __restrict__ H = pg.H[prob];
+      const float alpha = pg.alpha[prob], beta = pg.beta[prob];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float v[2][16];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) v[u][e] = acc[t][u][e];
+        big_epilogue_rows(H, ldh, ti, tj, wm, wn, lane, t, v, alpha, beta);
+      }
+    } else {
+      float* __restrict__ part = plan.ws + ((long)(bid - plan.dp_tiles) * 2 + seg) * BTILE_FLOATS;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) part[big_part_index(wave, t, u, e, lane)] = acc[t][u][e];
+    }
+  }
+}
+
+// Four workgroups per K-split tile: sum its partial tiles in run order, then the usual epilogue.
+__global__ __launch_bounds__(512) void hessian16_big_fixup(ProbGroup pg, BigPlan plan, int ldh, int C, int nk_all) {
+  const int l = blockIdx.x;
+  const int tile = plan.dp_tiles + l;
+  const int prob = tile / plan.tiles_per_prob;
+  int ti, tj;
+  hessian_tile_of(tile - prob * plan.tiles_per_prob, C / BT, ti, tj);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int first = l * nk_all, last = first + nk_all - 1;
+  const int w0 = first / plan.chunk, w1 = min(last / plan.chunk, plan.workers - 1);
+  float* __restrict__ H = pg.H[prob];
+  const float alpha = pg.alpha[prob], beta = pg.beta[prob];
+  {
+    const int t = blockIdx.y;                                 // one 32-row block pair per workgroup
+    float v[2][16];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[u][e] = 0.f;
+    for (int w = w0; w <= w1; ++w) {
+      const int seg = (w * plan.chunk < first) ? 1 : 0;       // the run began in the previous tile
+      const float* __restrict__ part = plan.ws + ((long)w * 2 + seg) * BTILE_FLOATS;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[u][e] += part[big_part_index(wave, t, u, e, lane)];
+    }
+    big_epilogue_rows(H, ldh, ti, tj, wm, wn, lane, t, v, alpha, beta);
+  }
+}
+
 // A[r][c] = A[c][r] for r > c, through a 32x33 LDS tile so both sides stay coalesced.
 __global__ __launch_bounds__(256) void symmetrize_kernel(float* __restrict__ A, int lda, int n) {
   __shared__ float t[32][33];
@@ -384,6 +688,62 @@ static int hessian_launch(const HostProb* probs, int n_prob, int ldh, int n_x, i
     bool aligned = (ldx % 8 == 0) && (tokens % HBK == 0) && (C % GBM == 0);
     for (int p = 0; p < n_prob; ++p)
       for (int i = 0; i < n_x; ++i) aligned = aligned && (reinterpret_cast<uintptr_t>(probs[p].xs[i]) % 16 == 0);
+    static const int big_env = [] { const char* e = getenv("GPTQ_HESS_BIG"); return e ? atoi(e) : 1; }();
+    // GPTQ_HESS_BIG: 0 = 128 x 128 kernel only, 1 = default, 2 = 256 x 256 kernel whenever the shape allows,
+    //                3 = like 2 but without the K-split last round
+    const long big_tiles = (long)(C / BT) * (C / BT + 1) / 2 * n_prob;
+    if (aligned && big_env && C % BT == 0 && tokens % BBK == 0 && (big_env >= 2 || big_tiles >= 100)) {
+      const int blocks256 = (C / BT) * (C / BT + 1) / 2;
+      int dev = 0, n_cu = 256;
+      GPTQ_CHECK_HIP(hipGetDevice(&dev));
+      GPTQ_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+      for (int p0 = 0; p0 < n_prob; p0 += MAX_PROB) {
+        const int np = std::min(MAX_PROB, n_prob - p0);
+        for (int i0 = 0; i0 < n_x; i0 += MAX_XLIST) {
+          const int nx = std::min(MAX_XLIST, n_x - i0);
+          ProbGroup pg{};
+          for (int p = 0; p < np; ++p) {
+            pg.H[p] = probs[p0 + p].H;
+            pg.alpha[p] = i0 == 0 ? probs[p0 + p].alpha : 1.f;
+            pg.beta[p] = probs[p0 + p].beta;
+            for (int i = 0; i < nx; ++i) pg.x[p].p[i] = static_cast<const unsigned short*>(probs[p0 + p].xs[i0 + i]);
+          }
+          const int total = np * blocks256, nk_all = tokens / BBK * nx;
+          BigPlan plan{blocks256, total, 0, 0, 1, nullptr};
+          const int full = total / n_cu * n_cu, left = total - full;
+          // cut the last round along K when it would run under 90 % full and a run still has >= 8 stages
+          if (big_env != 3 && left > 0 && left * 10 < n_cu * 9 && (long)left * nk_all >= 8L * n_cu) {
+            plan.dp_tiles = full;
+            plan.left_tiles = left;
+            plan.workers = n_cu;
+            plan.chunk = cdiv((long)left * nk_all, n_cu);
+            plan.workers = cdiv((long)left * nk_all, plan.chunk);
+            plan.ws = static_cast<float*>(scratch_buffer(s, sizeof(float) * 2 * BTILE_FLOATS * (size_t)plan.workers));
+            GPTQ_CHECK_ARG(plan.ws != nullptr, "gptq_hessian_accum: cannot allocate the %zu-byte split-K workspace",
+                           sizeof(float) * 2 * BTILE_FLOATS * (size_t)plan.workers);
+          }
+          const int grid = plan.dp_tiles + plan.workers;
+#define HBIG(BF, RG, AB)                                                                                      \
+  do {                                                                                                        \
+    const size_t lds_b = (size_t)(RG) * BSTAGE;                                                               \
+    GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_big_kernel<BF, RG, AB>),      \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));              \
+    hessian16_big_kernel<BF, RG, AB><<<grid, 512, lds_b, s>>>(pg, plan, ldh, nx, ldx, C, tokens);             \
+  } while (0)
+          static const int bring_env = [] { const char* e = getenv("GPTQ_HESS_RING"); return e ? atoi(e) : BRING_DEFAULT; }();
+          static const int babl_env = [] { const char* e = getenv("GPTQ_HESS_ABLATE"); return e ? atoi(e) : 0; }();
+          if (x_dtype == GPTQ_BF16) HBIG(true, BRING_DEFAULT, 0);
+          else if (babl_env == 1) HBIG(false, BRING_DEFAULT, 1);
+          else if (babl_env == 2) HBIG(false, BRING_DEFAULT, 2);
+          else if (bring_env == 5) HBIG(false, 5, 0);
+          else HBIG(false, BRING_DEFAULT, 0);
+#undef HBIG
+          if (plan.left_tiles > 0) hessian16_big_fixup<<<dim3(plan.left_tiles, 4), 512, 0, s>>>(pg, plan, ldh, C, nk_all);
+        }
+      }
+      GPTQ_CHECK_LAUNCH("hessian16_big_kernel");
+      return GPTQ_OK;
+    }
     if (aligned) {
       static const int ring_env = [] { const char* e = getenv("GPTQ_HESS_RING"); return e ? atoi(e) : RING_DEFAULT; }();
       const size_t lds = (size_t)ring_env * DSTAGE;

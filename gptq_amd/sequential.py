@@ -23,7 +23,7 @@ from typing import Dict, Iterable, List, Optional
 import torch
 import torch.nn as nn
 
-from .gptq import GPTQ
+from .gptq import GPTQ, fasterquant_many
 from .modelutils import find_layers
 from .quant import Quantizer, quantize
 
@@ -178,10 +178,9 @@ def quantize_sequential(model, dataloader, dev, args: QuantArgs, group=None) -> 
                 outs[j] = _run_layer(layer, inps[j], kwargs)
             for h in handles:
                 h.remove()
+            fasterquant_many(list(solvers.values()), blocksize=args.blocksize, percdamp=args.percdamp,
+                             groupsize=args.groupsize, actorder=args.act_order, static_groups=args.static_groups)
             for name in subset:
-                solvers[name].fasterquant(blocksize=args.blocksize, percdamp=args.percdamp, groupsize=args.groupsize,
-                                          actorder=args.act_order, static_groups=args.static_groups,
-                                          layer_name=f"{i}.{name}")
                 key = f"{fam['prefix']}.{i}.{name}"
                 quantizers[key] = solvers[name].quantizer
                 records.append(dict(name=key, error=solvers[name].error))

@@ -343,6 +343,46 @@ def test_fasterquant_fp16_layer_and_hessian_from_add_batch(G, O):
     assert gp.H is None
 
 
+@pytest.mark.parametrize("kw", [dict(groupsize=-1), dict(groupsize=128, static_groups=True),
+                                dict(groupsize=128, actorder=True)])
+def test_fasterquant_many_matches_one_by_one(G, kw):
+    """Concurrent-stream solves of a block's Linears == the serial loop, bit for bit (opt.py:189-214)."""
+    gen = torch.Generator().manual_seed(77)
+    shapes = [(256, 512), (384, 512), (512, 256), (128, 1024), (256, 512)]
+
+    def build():
+        solvers = []
+        g2 = torch.Generator().manual_seed(78)
+        for (R, C) in shapes:
+            lin = make_linear((torch.randn(R, C, generator=g2) * 0.02).half().cuda())
+            gp = G.GPTQ(lin)
+            gp.quantizer = G.Quantizer(); gp.quantizer.configure(4, perchannel=True, sym=False, mse=False)
+            for _ in range(3):
+                x = (torch.randn(1, 300, C, generator=g2) * (1 + torch.arange(C) % 5)).half().cuda()
+                gp.add_batch(x, None)
+            solvers.append(gp)
+        return solvers
+
+    G.gptq.VERBOSE = False
+    a = build()
+    for gp in a:
+        gp.fasterquant(blocksize=128, percdamp=0.01, **kw)
+    b = build()
+    G.fasterquant_many(b, blocksize=128, percdamp=0.01, **kw)
+    # a second round right away re-uses the pooled streams while the first results are still referenced
+    c = build()
+    G.fasterquant_many(c, blocksize=128, percdamp=0.01, max_concurrent=2, **kw)
+    for x, y, z in zip(a, b, c):
+        for other in (y, z):
+            assert torch.equal(x.codes, other.codes)
+            assert torch.equal(x.layer.weight.data, other.layer.weight.data)
+            assert torch.equal(x.quantizer.scale, other.quantizer.scale)
+            assert torch.equal(x.quantizer.zero, other.quantizer.zero)
+            assert x.error == other.error
+            if kw.get("actorder"):
+                assert torch.equal(x.perm, other.perm)
+
+
 # ----------------------------------------------------------------- a9 / a12 pack
 @pytest.mark.parametrize("bits", [3, 4])
 def test_pack_golden_bit_exact(G, bits):
