@@ -401,8 +401,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void panel_kernel(float* __restrict__
 }
 
 // Trailing update:  A[m][n] -= sum_k P[m][k] P[n][k]  on the lower tiles of the remaining matrix.
-// `first` offsets the linear tile id: id 0 is the next diagonal tile (kb+1, kb+1), which the look-ahead
-// schedule updates on its own so that the next diagonal factorization can start early.
+// `first` offsets the linear tile id: ids [0, nrem) are the tiles of the next block column, which the look-ahead
+// schedule updates on its own so that the next factorization + panel solve can start early.
 __global__ __launch_bounds__(GEMM_THREADS) void syrk_kernel(float* __restrict__ A, int Cp, int kb, int nrem,
                                                             int first) {
   __shared__ __attribute__((aligned(16))) float smem[GEMM_LDS_FLOATS];
@@ -425,9 +425,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void syrk_kernel(float* __restrict__ 
 //   step 2:  X = -Cc^-1 * T  into the lower triangle of Linv.
 __global__ __launch_bounds__(GEMM_THREADS) void trtri_step1_kernel(const float* __restrict__ L,
                                                                    float* __restrict__ Linv, int Cp,
-                                                                   int nblk, int s) {
+                                                                   int nblk, int s, int p0) {
   __shared__ __attribute__((aligned(16))) float smem[GEMM_LDS_FLOATS];
-  const int p = blockIdx.y, ti = blockIdx.x / s, tj = blockIdx.x % s;
+  const int p = blockIdx.y + p0, ti = blockIdx.x / s, tj = blockIdx.x % s;
   const int a0 = 2 * p * s, cb0 = a0 + s;
   if (cb0 + ti >= nblk) return;
   const long rm = (long)(cb0 + ti) * NB, cn = (long)(a0 + tj) * NB, ka = (long)a0 * NB;
@@ -439,9 +439,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void trtri_step1_kernel(const float* 
 }
 
 __global__ __launch_bounds__(GEMM_THREADS) void trtri_step2_kernel(float* __restrict__ Linv, int Cp,
-                                                                   int nblk, int s) {
+                                                                   int nblk, int s, int p0) {
   __shared__ __attribute__((aligned(16))) float smem[GEMM_LDS_FLOATS];
-  const int p = blockIdx.y, ti = blockIdx.x / s, tj = blockIdx.x % s;
+  const int p = blockIdx.y + p0, ti = blockIdx.x / s, tj = blockIdx.x % s;
   const int a0 = 2 * p * s, cb0 = a0 + s;
   if (cb0 + ti >= nblk) return;
   const long rm = (long)(cb0 + ti) * NB, cn = (long)(a0 + tj) * NB, kc = (long)cb0 * NB;
@@ -493,11 +493,13 @@ extern "C" int gptq_hinv_upper(float* H, int ldh, int C, float percdamp, const i
 
   diag_mean_kernel<<<1, 256, 0, s>>>(H, ldh, C, percdamp, damp, info);
   build_abar_kernel<<<dim3(cdiv(Cp, 256), Cp), 256, 0, s>>>(H, ldh, C, Cp, perm, damp, A);
-  // Look-ahead: the diagonal factorization of panel kb+1 only needs tile (kb+1, kb+1), so that tile is
-  // updated on the caller's stream right after panel kb and the rest of the trailing SYRK runs on a
-  // helper stream underneath the (serial, latency-bound) factorization.
+  // Look-ahead: the factorization and the panel solve of block column kb+1 only need that column, so it is
+  // updated on the caller's stream right after panel kb and the rest of the trailing SYRK runs on a helper
+  // stream underneath them (they are serial and latency-bound).
   SideCtx* sc = (lookahead_mask() & 1) ? side_ctx(s) : nullptr;
-  bool side_busy = false;
+  bool side_busy = false, tri_on_side = false;
+  int tri_done[32] = {};                                         // pairs already launched, per level
+  static const int tri_overlap = [] { const char* e = getenv("GPTQ_TRTRI_OVERLAP"); return e ? atoi(e) : 0; }();
   static const int potrf_v2 = [] { const char* e = getenv("GPTQ_POTRF_V2"); return e ? atoi(e) : 1; }();
   static const int potrf_abl = [] { const char* e = getenv("GPTQ_POTRF_ABLATE"); return e ? atoi(e) : 0; }();
   if (potrf_v2)
@@ -508,26 +510,48 @@ extern "C" int gptq_hinv_upper(float* H, int ldh, int C, float percdamp, const i
     else potrf_inv_diag_kernel<<<1, 512, 0, s>>>(A, Linv, Cp, kb, info);
     const int nrem = nblk - kb - 1;
     if (nrem <= 0) break;
-    if (side_busy) GPTQ_CHECK_HIP(hipStreamWaitEvent(s, sc->side_done, 0));   // SYRK of panel kb-1 finished
     panel_kernel<<<nrem, GEMM_THREADS, 0, s>>>(A, Linv, Cp, kb);
     const int ntiles = nrem * (nrem + 1) / 2;
-    if (sc && ntiles > 1) {
-      syrk_kernel<<<1, GEMM_THREADS, 0, s>>>(A, Cp, kb, nrem, 0);
+    if (sc && ntiles > nrem) {
+      // block column kb+1 (tile ids [0, nrem)) is all the next factorization + panel need: it stays on the
+      // caller's stream; the other columns are updated on the helper stream under them.  Column kb+1 was last
+      // written by the previous step's helper part, hence the wait.
+      if (side_busy) GPTQ_CHECK_HIP(hipStreamWaitEvent(s, sc->side_done, 0));
+      syrk_kernel<<<nrem, GEMM_THREADS, 0, s>>>(A, Cp, kb, nrem, 0);
       GPTQ_CHECK_HIP(hipEventRecord(sc->main_done, s));
       GPTQ_CHECK_HIP(hipStreamWaitEvent(sc->stream, sc->main_done, 0));
-      syrk_kernel<<<ntiles - 1, GEMM_THREADS, 0, sc->stream>>>(A, Cp, kb, nrem, 1);
+      syrk_kernel<<<ntiles - nrem, GEMM_THREADS, 0, sc->stream>>>(A, Cp, kb, nrem, nrem);
       GPTQ_CHECK_HIP(hipEventRecord(sc->side_done, sc->stream));
       side_busy = true;
+      // Pairs of the recursive-doubling inverse whose blocks are all final (the pair at level sz ending at block
+      // kb) go out on the helper stream now, level by level, instead of after the whole factorization.
+      int lvl = 0;
+      for (int sz = 1; tri_overlap && sz < nblk; sz *= 2, ++lvl)
+        while ((tri_done[lvl] + 1) * 2 * sz <= kb + 1) {
+          trtri_step1_kernel<<<dim3(sz * sz, 1), GEMM_THREADS, 0, sc->stream>>>(A, Linv, Cp, nblk, sz, tri_done[lvl]);
+          trtri_step2_kernel<<<dim3(sz * sz, 1), GEMM_THREADS, 0, sc->stream>>>(Linv, Cp, nblk, sz, tri_done[lvl]);
+          ++tri_done[lvl];
+          tri_on_side = true;
+        }
     } else {
+      if (side_busy) GPTQ_CHECK_HIP(hipStreamWaitEvent(s, sc->side_done, 0));
       syrk_kernel<<<ntiles, GEMM_THREADS, 0, s>>>(A, Cp, kb, nrem, 0);
       side_busy = false;
     }
   }
+  if (tri_on_side) {                                             // everything the helper stream still holds
+    GPTQ_CHECK_HIP(hipEventRecord(sc->side_done, sc->stream));
+    side_busy = true;
+  }
   if (side_busy) GPTQ_CHECK_HIP(hipStreamWaitEvent(s, sc->side_done, 0));
-  for (int sz = 1; sz < nblk; sz *= 2) {
-    const int pairs = cdiv(nblk, 2 * sz);
-    trtri_step1_kernel<<<dim3(sz * sz, pairs), GEMM_THREADS, 0, s>>>(A, Linv, Cp, nblk, sz);
-    trtri_step2_kernel<<<dim3(sz * sz, pairs), GEMM_THREADS, 0, s>>>(Linv, Cp, nblk, sz);
+  {
+    int lvl = 0;
+    for (int sz = 1; sz < nblk; sz *= 2, ++lvl) {
+      const int pairs = cdiv(nblk, 2 * sz), left = pairs - tri_done[lvl];
+      if (left <= 0) continue;
+      trtri_step1_kernel<<<dim3(sz * sz, left), GEMM_THREADS, 0, s>>>(A, Linv, Cp, nblk, sz, tri_done[lvl]);
+      trtri_step2_kernel<<<dim3(sz * sz, left), GEMM_THREADS, 0, s>>>(Linv, Cp, nblk, sz, tri_done[lvl]);
+    }
   }
   flip_to_upper_kernel<<<dim3(cdiv(C, 256), C), 256, 0, s>>>(Linv, Cp, C, H, ldh);
   GPTQ_CHECK_LAUNCH("gptq_hinv_upper");

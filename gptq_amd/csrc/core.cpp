@@ -20,7 +20,12 @@ SideCtx* side_ctx(hipStream_t main) {
   const auto key = std::make_pair(dev, main);
   auto it = table.find(key);
   if (it != table.end()) return &it->second;
-  if (table.size() >= 256) return nullptr;                      // callers then run serially
+  // HIP maps streams onto few hardware queues (4 by default) and streams sharing one serialize: by default only
+  // the first caller stream per device gets a helper (GPTQ_SIDE_STREAMS raises that); the others run serially.
+  static const int limit = [] { const char* e = getenv("GPTQ_SIDE_STREAMS"); return e ? atoi(e) : 1; }();
+  int mine = 0;
+  for (const auto& kv : table) mine += kv.first.first == dev;
+  if (mine >= limit) return nullptr;
   SideCtx c;
   if (hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
   if (hipEventCreateWithFlags(&c.main_done, hipEventDisableTiming) != hipSuccess) return nullptr;
@@ -50,7 +55,7 @@ void* scratch_buffer(hipStream_t main, size_t bytes) {
 int lookahead_mask() {
   static int mask = [] {
     const char* e = getenv("GPTQ_LOOKAHEAD");
-    return e ? atoi(e) : 2;
+    return e ? atoi(e) : 3;
   }();
   return mask;
 }

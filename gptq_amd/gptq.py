@@ -80,8 +80,9 @@ def flush_pending():
 
 
 _SOLVE_STREAMS = {}   # device -> pool of streams for fasterquant_many
-SOLVE_STREAMS = 2     # concurrent solves per device (each also owns a look-ahead helper stream; HIP maps
-                      # streams onto 4 hardware queues by default, more streams than that serialize falsely)
+SOLVE_STREAMS = 3     # concurrent solves per device: the caller's stream (it carries the largest solve and owns the
+                      # library's look-ahead helper stream) + 2 more = the 4 hardware queues HIP uses by default;
+                      # streams beyond the queues serialize falsely
 
 
 def fasterquant_many(solvers, blocksize=128, percdamp=.01, groupsize=-1, actorder=False, static_groups=False,
