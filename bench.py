@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--hessian-defer", type=int, default=8,
                     help="hook inputs folded into H per launch (gptq_amd.gptq.HESSIAN_DEFER; 1 = per call like the reference)")
     ap.add_argument("--serial-solve", action="store_true", help="solve the Linears one by one instead of on concurrent streams")
+    ap.add_argument("--no-shared-inputs", action="store_true",
+                    help="give q/k/v private calibration tensors (their Hessians are then accumulated three times)")
     ap.add_argument("--solve-streams", type=int, default=0, help="concurrent solves (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=128, help="calibration samples in the CPU baseline sample")
@@ -98,10 +100,24 @@ def main():
     # ---- synthetic inputs, resident in HBM (W ~ N(0, 0.02^2), X ~ N(0,1)*(1 + c mod 7)) ----
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)
     weights = {i: (torch.randn(units[i].rows, units[i].cols, device=dev, generator=gen) * 0.02).half() for i in mine}
-    acts = {}
-    for C in sorted({units[i].cols for i in mine}):
+    # Calibration inputs per Linear.  As in the model, q/k/v of a block are fed the SAME tensor (opt.py:184-185 hooks
+    # fire on the one LayerNorm output); out_proj, fc1 and fc2 each see their own.  --no-shared-inputs gives every
+    # Linear a private tensor (then no Hessian is shared, see gptq_amd.gptq.SHARE_INPUT_HESSIANS).
+    def make_acts(C):
         chan = (1 + torch.arange(C, device=dev) % 7).half()
-        acts[C] = torch.randn(args.nsamples, SEQLEN, C, device=dev, generator=gen, dtype=torch.float16) * chan
+        return torch.randn(args.nsamples, SEQLEN, C, device=dev, generator=gen, dtype=torch.float16) * chan
+    acts = {}
+    shared = {}
+    for i in mine:
+        u = units[i]
+        blk = i // 6                                   # units are laid out block by block: q,k,v,out,fc1,fc2
+        if u.name.split(".")[-1] in ("q_proj", "k_proj", "v_proj") and not args.no_shared_inputs:
+            key = (blk, "qkv")
+            if key not in shared:
+                shared[key] = make_acts(u.cols)
+            acts[i] = shared[key]
+        else:
+            acts[i] = make_acts(u.cols)
     torch.cuda.synchronize()
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
@@ -130,7 +146,7 @@ def main():
         e0.record()
         for j in range(args.nsamples):
             for i in mine:
-                solvers[i].add_batch(acts[units[i].cols][j:j + 1], None)
+                solvers[i].add_batch(acts[i][j:j + 1], None)
         gmod.flush_pending()
         e1.record()
         gmod.FLUSH_EVENTS = None
@@ -158,8 +174,6 @@ def main():
             for s0, s1, s2 in solve_ev:
                 phase_ms["solve"] += s0.elapsed_time(s1)
                 phase_ms["pack"] += s1.elapsed_time(s2)
-            for i in mine:
-                hess_flops += args.nsamples * float(SEQLEN) * units[i].cols * units[i].cols   # upper-triangle SYRK: S*C^2
         if world > 1:
             a0, a1 = ev(), ev()
             a0.record()
@@ -203,6 +217,7 @@ def main():
                                "fc2 2048x8192; 4-bit asym, groupsize 128 (static groups), blocksize 128, percdamp 0.01",
                    "nsamples": args.nsamples, "seqlen": SEQLEN, "blocks_per_step": world, "hessian_defer": args.hessian_defer,
                    "scope": "add_batch x nsamples + fasterquant + 4-bit pack for every Linear",
+                   "calibration_inputs": "private tensor per Linear" if args.no_shared_inputs else "q,k,v share one input tensor (as in the model): their common Hessian is accumulated once; out_proj, fc1, fc2 private",
                    "parallelism": "1 GPU" if world == 1 else f"module-sharded over {world} GPUs, all-gather of packed weights"},
     }
     if rank == 0:
@@ -213,6 +228,8 @@ def main():
         # that Linear's launch sequence / number of launches (rocprofv3 summary under profiles/ agrees).
         ub = units[big]
         per_launch = max(1, args.hessian_defer)
+        # executed algorithmic flops: S*C^2 (upper-triangle SYRK) per problem and slab of every Hessian launch
+        hess_flops = sum(nprob * nslab * float(SEQLEN) * C_ * C_ for (C_, nprob, nslab, a, b) in flush_events)
         durs = [a.elapsed_time(b) for (C_, nprob, nslab, a, b) in flush_events if C_ == ub.cols and nslab == per_launch]
         n_launch = len(durs)
         launch_ms = sum(durs) / max(n_launch, 1)

@@ -169,7 +169,7 @@ struct QuantBlockArgs {
 
 // One 32-column phase PH of the block (compile-time, so every "is there a later group" test and every
 // register index below is static: no branches inside, no register shuffling between phases).
-template <int NPH, bool GROUPED, int PH>
+template <int NPH, bool GROUPED, int PH, int ABL = 0>   // ABL: timing-only diagnostic builds (results are wrong)
 __device__ __forceinline__ void quant_phase(const QuantBlockArgs& a, float (&w)[8 * NPH], float* Us,
                                             const int* grp, const int* cmap, float sc, float zr, bool active,
                                             long rbase, float* wrow, int c, int tid, float& loss) {
@@ -185,7 +185,7 @@ __device__ __forceinline__ void quant_phase(const QuantBlockArgs& a, float (&w)[
     // columns past `count` (tail block) are padded: zero weights, identity U rows and a unit grid
     // make their steps exact no-ops, so the hot loop below carries no `count` branches
     float v = (k == i) ? 1.f : 0.f;
-    if (i < a.count && k >= i && k < a.count) v = a.U[(long)(a.i1 + i) * a.ldu + a.i1 + k];
+    if (ABL != 3 && i < a.count && k >= i && k < a.count) v = a.U[(long)(a.i1 + i) * a.ldu + a.i1 + k];
     Us[(il * 4 + (k & 3)) * LDCL + (k >> 2)] = v;
   }
   __syncthreads();
@@ -234,10 +234,10 @@ __device__ __forceinline__ void quant_phase(const QuantBlockArgs& a, float (&w)[
       else if (tail && 32 * ph + il >= a.count) { gsc = 1.f; gzr = 0.f; }
       const float* urow = Us + il * 4 * LDCL;
       const float x = cur[cc];
-      const float code = affine_code(x, gsc, gzr, a.maxq);     // gptq.py:262-264
+      const float code = ABL == 2 ? fminf(fmaxf(rintf(x * gsc) + gzr, 0.f), a.maxq) : affine_code(x, gsc, gzr, a.maxq);     // gptq.py:262-264
       const float q = gsc * (code - gzr);
       const float d = urow[cc * LDCL + 8 * ph + t];            // Hinv1[i, i]
-      const float err = (x - q) / d;                           // gptq.py:269
+      const float err = ABL == 2 ? (x - q) * d : (x - q) / d;  // gptq.py:269
       err4[cc] = err;
       loss += err * err;                                       // (w-q)^2/d^2, gptq.py:267 (tolerance-level)
       if (c == cc) { wt[t] = q; e[t] = err; cd[t] = code; }
@@ -249,7 +249,7 @@ __device__ __forceinline__ void quant_phase(const QuantBlockArgs& a, float (&w)[
     //     order (column i, then i+1, ...): independent across elements, so the LDS reads batch up
     //     and nothing here sits on the chain above.
 #pragma unroll
-    for (int cc = 0; cc < 4; ++cc) {
+    for (int cc = 0; cc < (ABL == 1 ? 0 : 4); ++cc) {
       const float* ul = Us + (4 * t + cc) * 4 * LDCL + c * LDCL;
       const float err = err4[cc];
 #pragma unroll
@@ -271,7 +271,7 @@ __device__ __forceinline__ void quant_phase(const QuantBlockArgs& a, float (&w)[
   }
 }
 
-template <int NPH, bool GROUPED>
+template <int NPH, bool GROUPED, int ABL = 0>
 __global__ __launch_bounds__(256) void quant_block_kernel(QuantBlockArgs a) {
   constexpr int B = 32 * NPH;
   constexpr int NREG = 8 * NPH;
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void quant_block_kernel(QuantBlockArgs a) {
   }
   float loss = 0.f;
 
-#define QPHASE(P) if constexpr (NPH > P) quant_phase<NPH, GROUPED, P>(a, w, Us, grp, cmap, sc, zr, active, rbase, wrow, c, tid, loss)
+#define QPHASE(P) if constexpr (NPH > P) quant_phase<NPH, GROUPED, P, ABL>(a, w, Us, grp, cmap, sc, zr, active, rbase, wrow, c, tid, loss)
   QPHASE(0); QPHASE(1); QPHASE(2); QPHASE(3); QPHASE(4); QPHASE(5); QPHASE(6); QPHASE(7);
 #undef QPHASE
   if (active && c == 0) a.loss[row] += 0.5f * loss;               // gptq.py:274
@@ -363,6 +363,14 @@ extern "C" int gptq_quantize_rows(float* X, int ldx, int R, int C, const float* 
 
 static int launch_quant_block(const QuantBlockArgs& a, int blocksize, bool grouped, hipStream_t s) {
   const int grid = cdiv(a.R, 64);
+  static const int abl = [] { const char* e = getenv("GPTQ_QB_ABLATE"); return e ? atoi(e) : 0; }();
+  if (abl && blocksize == 128 && grouped) {                      // diagnostic builds, timing only
+    if (abl == 1) quant_block_kernel<4, true, 1><<<grid, 256, 0, s>>>(a);
+    else if (abl == 2) quant_block_kernel<4, true, 2><<<grid, 256, 0, s>>>(a);
+    else quant_block_kernel<4, true, 3><<<grid, 256, 0, s>>>(a);
+    GPTQ_CHECK_LAUNCH("quant_block_kernel");
+    return GPTQ_OK;
+  }
 #define QB_CASE(NPH)                                                                  \
   case 32 * NPH:                                                                      \
     if (grouped) quant_block_kernel<NPH, true><<<grid, 256, 0, s>>>(a);               \

@@ -44,6 +44,19 @@ _DIRTY = {}     # id -> GPTQ objects holding deferred hook inputs
 FLUSH_EVENTS = None   # set to a list to collect (C, n_problems, n_slabs, start_event, end_event) per Hessian launch
 
 
+# Linears that are fed the SAME input tensor from the same forward passes (q/k/v, gate/up) accumulate the same
+# Hessian; the reference recomputes it per Linear (SURVEY 8a "identical H recomputed for k/v/q").  With
+# SHARE_INPUT_HESSIANS the objects whose deferred inputs are the same device buffers (pointer, shape, strides,
+# dtype) from their very first add_batch on keep ONE running H: the first object (the leader) owns it, the others
+# copy it when they need their own (solve, `.H`, diverging inputs).  What every object ends up with is bit for bit
+# what it would have computed alone -- the kernel, its inputs and the order of the updates are the same.
+SHARE_INPUT_HESSIANS = True
+
+
+def _input_signature(o):
+    return tuple((x.data_ptr(), tuple(x.shape), tuple(x.stride()), x.dtype, b) for x, b in o._pending)
+
+
 def flush_pending():
     """Fold every deferred hook input into its H.  Objects whose pending inputs have the same shape
     (the Linears of one block that share in_features) go out as ONE grouped launch
@@ -52,8 +65,33 @@ def flush_pending():
     global _DIRTY
     objs = [o for o in _DIRTY.values() if o._pending and o._H is not None]
     _DIRTY = {}
-    groups = {}
+    if not objs:
+        return
+    sigs = {id(o): _input_signature(o) for o in objs}
+    # followers whose inputs stopped matching their leader's take their own copy of H first
     for o in objs:
+        L = o._leader
+        if L is not None and (id(L) not in sigs or sigs[id(L)] != sigs[id(o)]):
+            o._materialize()
+    for o in objs:
+        for f in list(o._followers):
+            if id(f) not in sigs:                       # the leader moves on alone
+                f._materialize()
+    # fresh objects (no update yet) with identical inputs join the first of them
+    if SHARE_INPUT_HESSIANS:
+        fresh = {}
+        for o in objs:
+            if o._fresh and o._leader is None and not o._followers:
+                key = (o.dev, o.columns, sigs[id(o)])
+                L = fresh.setdefault(key, o)
+                if L is not o:
+                    o._leader = L
+                    L._followers.append(o)
+    for o in objs:
+        o._fresh = False
+    work = [o for o in objs if o._leader is None]
+    groups = {}
+    for o in work:
         x0 = o._pending[0][0]
         key = (o.dev, o.columns, x0.shape[0], x0.dtype, x0.stride(0), len(o._pending),
                sum(b for _, b in o._pending), o._H.stride(0))
@@ -73,10 +111,10 @@ def flush_pending():
                 if FLUSH_EVENTS is not None:
                     ev1.record()
                     FLUSH_EVENTS.append((C, len(chunk), n_x, ev0, ev1))
-            for o in chunk:
-                o._applied += batch
-                o._pending = []
-                o._lower_stale = True
+    for o in objs:
+        o._applied += sum(b for _, b in o._pending)
+        o._pending = []
+        o._lower_stale = True
 
 
 _SOLVE_STREAMS = {}   # device -> pool of streams for fasterquant_many
@@ -98,6 +136,9 @@ def fasterquant_many(solvers, blocksize=128, percdamp=.01, groupsize=-1, actorde
     if not solvers:
         return
     flush_pending()
+    for g in solvers:                    # shared running Hessians: private copies, on the caller's stream,
+        g._materialize()                 # before the solves fan out over the lanes
+        g._release_followers()
     by_dev = {}
     for g in solvers:
         by_dev.setdefault(g.dev, []).append(g)
@@ -154,6 +195,26 @@ class GPTQ:
         self.nsamples = 0
         self._pending = []          # deferred (x, batch) hook inputs, see HESSIAN_DEFER
         self._applied = 0           # samples already folded into _H
+        self._fresh = True          # no update folded in yet and H never assigned
+        self._leader = None         # object whose _H this one shares (SHARE_INPUT_HESSIANS)
+        self._followers = []        # objects sharing this one's _H
+
+    # -- shared running Hessians (SHARE_INPUT_HESSIANS) -------------------------------------------
+    def _materialize(self):
+        """Follower: take a private copy of the leader's H (its own, so far unused, buffer)."""
+        L = self._leader
+        if L is None:
+            return
+        self._leader = None
+        L._followers.remove(self)
+        if self._H is not None and L._H is not None:
+            self._H.copy_(L._H)
+            self._lower_stale = L._lower_stale
+
+    def _release_followers(self):
+        """Leader about to overwrite / drop its H: the followers copy it first."""
+        for f in list(self._followers):
+            f._materialize()
 
     # -- H stays reachable as a full symmetric tensor (SURVEY 8b); mirrored lazily -------------
     def _flush(self):
@@ -162,6 +223,7 @@ class GPTQ:
     @property
     def H(self):
         self._flush()
+        self._materialize()
         if self._H is not None and self._lower_stale:
             with torch.cuda.device(self.dev):
                 _lib.call("gptq_symmetrize", _lib.ptr(self._H), self._H.stride(0), self.columns, _lib.stream(self.dev))
@@ -172,11 +234,20 @@ class GPTQ:
     def H(self, value):
         self._pending = []
         _DIRTY.pop(id(self), None)
+        self._release_followers()
+        if self._leader is not None:
+            self._leader._followers.remove(self)
+            self._leader = None
+        self._fresh = False
         self._H = value
         self._lower_stale = False
 
     @H.deleter
     def H(self):
+        self._release_followers()
+        if self._leader is not None:
+            self._leader._followers.remove(self)
+            self._leader = None
         self._H = None
 
     def add_batch(self, inp, out):
@@ -235,6 +306,8 @@ class GPTQ:
             raise NotImplementedError("trits are outside the MI355X hot-path scope")
         tick = time.time()
         self._flush()
+        self._materialize()              # shared running Hessian: this object's own copy ...
+        self._release_followers()        # ... and the copies of those that share this one's
         W = self.layer.weight.data.clone()
         if isinstance(self.layer, nn.Conv2d):
             W = W.flatten(1)
@@ -308,6 +381,10 @@ class GPTQ:
         if DEBUG:
             self.inp1 = None
             self.out1 = None
+        self._release_followers()
+        if self._leader is not None:
+            self._leader._followers.remove(self)
+            self._leader = None
         self._H = None
         self._pending = []
         _DIRTY.pop(id(self), None)

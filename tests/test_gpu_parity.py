@@ -383,6 +383,76 @@ def test_fasterquant_many_matches_one_by_one(G, kw):
                 assert torch.equal(x.perm, other.perm)
 
 
+def _shared_setup(G, n=4, C=512, R=64, seed=5):
+    g2 = torch.Generator().manual_seed(seed)
+    objs = []
+    for _ in range(n):
+        lin = make_linear((torch.randn(R, C, generator=g2) * 0.02).half().cuda())
+        gp = G.GPTQ(lin)
+        gp.quantizer = G.Quantizer(); gp.quantizer.configure(4, perchannel=True, sym=False, mse=False)
+        objs.append(gp)
+    xs = [(torch.randn(1, 200, C, generator=g2) * (1 + torch.arange(C) % 5)).half().cuda() for _ in range(6)]
+    return objs, xs
+
+
+@pytest.mark.parametrize("defer", [1, 4])
+def test_shared_input_hessians_match_private_ones(G, defer):
+    """q/k/v-style objects fed the same tensors keep one running H; what each ends up with (H, codes) is bit for bit
+    what it computes alone; an object whose inputs diverge midway leaves the group with the right state."""
+    gm = G.gptq
+    gm.VERBOSE = False
+    old = (gm.HESSIAN_DEFER, gm.SHARE_INPUT_HESSIANS)
+    try:
+        results = {}
+        for share in (False, True):
+            gm.HESSIAN_DEFER, gm.SHARE_INPUT_HESSIANS = defer, share
+            objs, xs = _shared_setup(G)
+            other = xs[5]
+            for k in range(5):
+                objs[0].add_batch(xs[k], None)
+                objs[1].add_batch(xs[k], None)
+                objs[2].add_batch(xs[k] if k < 3 else other, None)      # diverges at the 4th sample
+                objs[3].add_batch(other, None)                            # never shares
+            gm.flush_pending()
+            if share:
+                assert objs[1]._leader is objs[0] and objs[2]._leader is None and objs[3]._leader is None
+            Hs = [o.H.clone() for o in objs]
+            objs[1].fasterquant(blocksize=128, percdamp=0.01, groupsize=128)   # a follower first, then its leader
+            objs[0].fasterquant(blocksize=128, percdamp=0.01, groupsize=128)
+            G.fasterquant_many(objs[2:], blocksize=128, percdamp=0.01, groupsize=128)
+            results[share] = (Hs, [o.codes.clone() for o in objs], [o.error for o in objs])
+        for a, b in zip(results[False][0], results[True][0]):
+            assert torch.equal(a, b)
+        for a, b in zip(results[False][1], results[True][1]):
+            assert torch.equal(a, b)
+        assert results[False][2] == results[True][2]
+    finally:
+        gm.HESSIAN_DEFER, gm.SHARE_INPUT_HESSIANS = old
+
+
+def test_shared_input_hessians_leader_freed_or_solved_first(G):
+    gm = G.gptq
+    gm.VERBOSE = False
+    objs, xs = _shared_setup(G, n=3)
+    for k in range(3):
+        for o in objs:
+            o.add_batch(xs[k], None)
+    gm.flush_pending()
+    assert objs[1]._leader is objs[0] and objs[2]._leader is objs[0]
+    ref = None
+    objs[0].fasterquant(blocksize=128, percdamp=0.01)          # leader consumes (overwrites) its H
+    assert objs[1]._leader is None and objs[2]._leader is None and not objs[0]._followers
+    objs[0].free()
+    H1, H2 = objs[1].H.clone(), objs[2].H.clone()
+    assert torch.equal(H1, H2)
+    X = torch.cat([x[0] for x in xs[:3]], 0).double()
+    ref = (2.0 / 3.0) * (X.t() @ X)
+    assert relfro(H1.double().cpu(), ref.cpu()) < 1e-6
+    G.fasterquant_many(objs[1:], blocksize=128, percdamp=0.01)
+    assert torch.equal(objs[1].quantizer.scale, objs[1].quantizer.scale)
+    assert objs[1].error > 0 and objs[2].error > 0
+
+
 # ----------------------------------------------------------------- a9 / a12 pack
 @pytest.mark.parametrize("bits", [3, 4])
 def test_pack_golden_bit_exact(G, bits):
