@@ -93,7 +93,10 @@ def main():
     # ---- unit list: `world` blocks' worth of Linears, dealt by cost -----------------------------
     units = [par.Unit(f"b{b}.{n}", r, c) for b in range(world) for (n, r, c) in SHAPES]
     costs = [par.unit_cost(u, args.nsamples, SEQLEN) for u in units]
-    assignment = par.assign_units(costs, world)
+    # q/k/v of a block are fed one tensor and share one Hessian: they travel together
+    bundles = [] if args.no_shared_inputs else [[6 * b, 6 * b + 1, 6 * b + 2] for b in range(world)]
+    assignment = par.assign_units(costs, world, bundles,
+                                  [par.hessian_cost(units[m[0]], args.nsamples, SEQLEN) for m in bundles])
     mine = assignment[rank]
     total_params = sum(u.params for u in units)
 

@@ -35,16 +35,34 @@ def unit_cost(u: Unit, nsamples: int, seqlen: int, blocksize: int = 128) -> floa
     return nsamples * seqlen * C * C + (2.0 / 3.0) * C ** 3 + R * C * C + R * C * blocksize
 
 
-def assign_units(costs: Sequence[float], world: int) -> List[List[int]]:
-    """Longest-processing-time-first: returns, per rank, the indices of its units (deterministic)."""
-    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+def hessian_cost(u: Unit, nsamples: int, seqlen: int) -> float:
+    """The Hessian term of `unit_cost` (Linears fed the same input share it, gptq.SHARE_INPUT_HESSIANS)."""
+    return float(nsamples) * seqlen * u.cols * u.cols
+
+
+def assign_units(costs: Sequence[float], world: int, bundles: Sequence[Sequence[int]] = (),
+                 shared: Sequence[float] = ()) -> List[List[int]]:
+    """Longest-processing-time-first: returns, per rank, the indices of its units (deterministic).
+    `bundles` lists groups of units that must land on the same rank (Linears fed the same input tensor: their
+    Hessian is accumulated once); `shared[b]` is the cost a bundle saves per member beyond the first."""
+    items: List[Tuple[float, List[int]]] = []
+    bundled = set()
+    for b, members in enumerate(bundles):
+        members = list(members)
+        if not members:
+            continue
+        save = (shared[b] if b < len(shared) else 0.0) * (len(members) - 1)
+        items.append((sum(costs[i] for i in members) - save, members))
+        bundled.update(members)
+    items += [(costs[i], [i]) for i in range(len(costs)) if i not in bundled]
+    order = sorted(range(len(items)), key=lambda k: (-items[k][0], items[k][1][0]))
     load = [0.0] * world
     out: List[List[int]] = [[] for _ in range(world)]
-    for i in order:
-        r = min(range(world), key=lambda k: (load[k], k))
-        out[r].append(i)
-        load[r] += costs[i]
-    return out
+    for k in order:
+        r = min(range(world), key=lambda j: (load[j], j))
+        out[r] += items[k][1]
+        load[r] += items[k][0]
+    return [sorted(a) for a in out]
 
 
 def packed_shapes(u: Unit, bits: int, groupsize: int) -> Tuple[Tuple[int, int], Tuple[int, int]]:

@@ -74,3 +74,22 @@ def test_allgather_packed_world2_gloo():
         ret = m.dict()
         mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
         assert dict(ret) == {0: True, 1: True}
+
+
+def test_assign_units_keeps_bundles_together():
+    """Linears fed the same input travel together (their Hessian is accumulated once) and loads stay balanced."""
+    from gptq_amd import parallel as par
+    shapes = [("q", 2048, 2048), ("k", 2048, 2048), ("v", 2048, 2048), ("o", 2048, 2048), ("fc1", 8192, 2048),
+              ("fc2", 2048, 8192)]
+    for world in (1, 2, 3, 8):
+        units = [par.Unit(f"b{b}.{n}", r, c) for b in range(world) for (n, r, c) in shapes]
+        costs = [par.unit_cost(u, 128, 2048) for u in units]
+        bundles = [[6 * b, 6 * b + 1, 6 * b + 2] for b in range(world)]
+        a = par.assign_units(costs, world, bundles, [par.hessian_cost(units[m[0]], 128, 2048) for m in bundles])
+        assert sorted(i for r in a for i in r) == list(range(len(units)))
+        for m in bundles:
+            assert len({next(r for r in range(world) if i in a[r]) for i in m}) == 1
+        loads = [sum(costs[i] for i in r) for r in a]
+        assert max(loads) <= 1.01 * min(loads)
+    # without bundles: plain LPT, deterministic
+    assert par.assign_units([5.0, 3.0, 3.0, 2.0, 2.0], 2) == [[0, 3], [1, 2, 4]]
