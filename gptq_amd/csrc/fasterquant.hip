@@ -169,25 +169,47 @@ struct QuantBlockArgs {
 
 // One 32-column phase PH of the block (compile-time, so every "is there a later group" test and every
 // register index below is static: no branches inside, no register shuffling between phases).
+// U rows of phase PH for the LDS image Us[il][k & 3][k >> 2] = U[i][k], k >= i (upper), else 0: thread `tid`
+// owns elements idx = tid + 256 j.  Columns past `count` (tail block) are padded: zero weights, identity U rows
+// and a unit grid make their steps exact no-ops, so the hot loop carries no `count` branches.
+template <int NPH, int PH, int ABL>
+__device__ __forceinline__ void stage_fetch(const QuantBlockArgs& a, int tid, float (&v)[32 * 32 * NPH / 256]) {
+  constexpr int B = 32 * NPH;
+#pragma unroll
+  for (int j = 0; j < 32 * B / 256; ++j) {
+    const int idx = tid + 256 * j;
+    const int il = idx / B, k = idx % B;
+    const int i = 32 * PH + il;
+    float x = (k == i) ? 1.f : 0.f;
+    if (ABL != 3 && i < a.count && k >= i && k < a.count) x = a.U[(long)(a.i1 + i) * a.ldu + a.i1 + k];
+    v[j] = x;
+  }
+}
+
+template <int NPH>
+__device__ __forceinline__ void stage_store(float* Us, int tid, const float (&v)[32 * 32 * NPH / 256]) {
+  constexpr int B = 32 * NPH;
+  constexpr int LDCL = 8 * NPH + 4;
+#pragma unroll
+  for (int j = 0; j < 32 * B / 256; ++j) {
+    const int idx = tid + 256 * j;
+    const int il = idx / B, k = idx % B;
+    Us[(il * 4 + (k & 3)) * LDCL + (k >> 2)] = v[j];
+  }
+}
+
 template <int NPH, bool GROUPED, int PH, int ABL = 0>   // ABL: timing-only diagnostic builds (results are wrong)
-__device__ __forceinline__ void quant_phase(const QuantBlockArgs& a, float (&w)[8 * NPH], float* Us,
+__device__ __forceinline__ void quant_phase(const QuantBlockArgs& a, float (&w)[8 * NPH], float* Us, float* Us_next,
                                             const int* grp, const int* cmap, float sc, float zr, bool active,
                                             long rbase, float* wrow, int c, int tid, float& loss) {
   constexpr int B = 32 * NPH;
   constexpr int NREG = 8 * NPH;
   constexpr int LDCL = NREG + 4;
   constexpr int ph = PH;
-  __syncthreads();
-  // stage the 32 U rows of this phase: Us[il][k & 3][k >> 2] = U[i][k], k >= i (upper), else 0
-  for (int idx = tid; idx < 32 * B; idx += 256) {
-    const int il = idx / B, k = idx % B;
-    const int i = 32 * ph + il;
-    // columns past `count` (tail block) are padded: zero weights, identity U rows and a unit grid
-    // make their steps exact no-ops, so the hot loop below carries no `count` branches
-    float v = (k == i) ? 1.f : 0.f;
-    if (ABL != 3 && i < a.count && k >= i && k < a.count) v = a.U[(long)(a.i1 + i) * a.ldu + a.i1 + k];
-    Us[(il * 4 + (k & 3)) * LDCL + (k >> 2)] = v;
-  }
+  constexpr int NST = 32 * B / 256;              // staged elements per thread
+  // The 32 U rows of this phase were staged into `Us` by the previous phase (or the kernel prologue); the rows
+  // of the NEXT phase are fetched into registers now and stored to the other buffer at the end, so their
+  // global / L2 latency hides under the column chain instead of preceding it.
   __syncthreads();
 
   float e[8], cd[8];
@@ -207,6 +229,9 @@ __device__ __forceinline__ void quant_phase(const QuantBlockArgs& a, float (&w)[
     }
   }
   const bool tail = !GROUPED && (32 * ph + 32 > a.count);   // block-uniform, false except in a tail block
+  // (issued after the grid loads above: vector-memory results return in order)
+  float nxt[NST];
+  if (PH + 1 < NPH) stage_fetch<NPH, PH + 1, ABL>(a, tid, nxt);
 
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
@@ -269,6 +294,7 @@ __device__ __forceinline__ void quant_phase(const QuantBlockArgs& a, float (&w)[
       a.Err[rbase * B + col] = (col < a.count) ? e[t] : 0.f;
     }
   }
+  if (PH + 1 < NPH) stage_store<NPH>(Us_next, tid, nxt);
 }
 
 template <int NPH, bool GROUPED, int ABL = 0>
@@ -276,7 +302,7 @@ __global__ __launch_bounds__(256) void quant_block_kernel(QuantBlockArgs a) {
   constexpr int B = 32 * NPH;
   constexpr int NREG = 8 * NPH;
   constexpr int LDCL = NREG + 4;               // padded class row (16-B aligned, conflict-free b128)
-  __shared__ __attribute__((aligned(16))) float Us[32 * 4 * LDCL];
+  __shared__ __attribute__((aligned(16))) float Usb[2][32 * 4 * LDCL];   // U rows of the current / next phase
   __shared__ int grp[B];
   __shared__ int cmap[B];
 
@@ -305,7 +331,12 @@ __global__ __launch_bounds__(256) void quant_block_kernel(QuantBlockArgs a) {
   }
   float loss = 0.f;
 
-#define QPHASE(P) if constexpr (NPH > P) quant_phase<NPH, GROUPED, P, ABL>(a, w, Us, grp, cmap, sc, zr, active, rbase, wrow, c, tid, loss)
+  {
+    float first[32 * B / 256];
+    stage_fetch<NPH, 0, ABL>(a, tid, first);
+    stage_store<NPH>(Usb[0], tid, first);
+  }
+#define QPHASE(P) if constexpr (NPH > P) quant_phase<NPH, GROUPED, P, ABL>(a, w, Usb[(P) & 1], Usb[((P) + 1) & 1], grp, cmap, sc, zr, active, rbase, wrow, c, tid, loss)
   QPHASE(0); QPHASE(1); QPHASE(2); QPHASE(3); QPHASE(4); QPHASE(5); QPHASE(6); QPHASE(7);
 #undef QPHASE
   if (active && c == 0) a.loss[row] += 0.5f * loss;               // gptq.py:274

@@ -654,6 +654,270 @@ __global__ __launch_bounds__(512) void hessian16_big_fixup(ProbGroup pg, BigPlan
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same 256 x 256 tile on v_mfma_f32_16x16x32_{f16,bf16} (GPTQ_HESS_SHAPE=16).  Cycles per flop are those of
+// the 32x32x16 form; which of the two the chip clocks higher under load is an empirical matter
+// (MI355X_MICROARCH.md "DVFS give-back" item 7), so both are built on the same tile and work split.
+// One k-step is a whole 32-token stage: A fragment of block t = channels 16t..16t+15 x tokens 8g..8g+7 for lane
+// group g = lane >> 4, i.e. two transposed reads (token rows 8g + q and 8g + 4 + q).  The two groups of a
+// half-wave read rows 8 apart in the same columns, so the image also XORs chunk bit 1 with token-row bit 3:
+// physical chunk = logical ^ ((row & 3) << 2) ^ (((row >> 3) & 1) << 1).  In block terms the lane reads block
+// (t ^ m), m = (g & 1) | (q << 1): address = lane_base ^ (32 t).
+// Stage = P1 (A blocks 0-3 x B, under the reads of A blocks 4-7) | barrier | P2 (A blocks 4-7 x B, under the
+// reads of the NEXT stage's A blocks 0-3 and B -- into the other B register set -- and the LDS-DMA pieces).
+// ---------------------------------------------------------------------------------------------
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <bool BF16>
+__device__ __forceinline__ f32x4v mfma16s(s16x8 a, s16x8 b, f32x4v c) {
+  if (BF16) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ long big16_part_index(int wave, int t, int u, int e, int lane) {
+  return ((((long)wave * 8 + t) * 4 + u) * 4 + e) * 64 + lane;
+}
+
+// H = alpha H + beta v for the 16-row blocks 2*t2 and 2*t2+1 of this wave (C/D map of the 16x16 MFMA:
+// col = lane & 15, row = 4 * (lane >> 4) + reg); loads batched before the stores
+__device__ __forceinline__ void big16_epilogue_rows(float* __restrict__ H, int ldh, int ti, int tj, int wm, int wn,
+                                                    int lane, int t2, const float (&v)[2][4][4], float alpha, float beta) {
+  const bool diag = ti == tj;
+  const int row0 = ti * BT + wm * 128 + 32 * t2 + 4 * (lane >> 4);
+  const int col0 = tj * BT + wn * 64 + (lane & 15);
+  float old[2][4][4];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = row0 + 16 * tt + e, col = col0 + 16 * u;
+        old[tt][u][e] = (!diag || row <= col) ? H[(long)row * ldh + col] : 0.f;
+      }
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = row0 + 16 * tt + e, col = col0 + 16 * u;
+        const float out = alpha * old[tt][u][e] + beta * v[tt][u][e];
+        if (!diag || row <= col) H[(long)row * ldh + col] = out;
+      }
+}
+
+// fragment reads: A block T (two reads) into FA[2T], FA[2T+1]; B block U into FB[2U], FB[2U+1]
+#define B16_RA(FA, T, TBLK) do { const unsigned ad_ = abase ^ (32u * (TBLK)); TR_READ(FA[2 * (T)], ad_, 0); TR_READ(FA[2 * (T) + 1], ad_, 1024); } while (0)
+#define B16_RB(FB, U) do { const unsigned ad_ = bbase ^ (32u * (bblk0 + (U))); TR_READ(FB[2 * (U)], ad_, 0); TR_READ(FB[2 * (U) + 1], ad_, 1024); } while (0)
+template <bool BF16>
+__global__ __launch_bounds__(512) void hessian16_big16_kernel(ProbGroup pg, BigPlan plan, int ldh, int nx,
+                                                              int ldx, int C, int tokens) {
+  constexpr int BRING = BRING_DEFAULT;
+  extern __shared__ __attribute__((aligned(1024))) char ring[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int spk = tokens / BBK;
+  const int nk_all = spk * nx;                                // even (host-checked), and so is every segment
+
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  const int m = (g & 1) | (q << 1);
+  const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)ring);
+  const unsigned lane_base = (8 * g + q) * 256 + 32 * m + 16 * (p >> 1) + 8 * (p & 1);
+  const unsigned oa = lds0 + wm * BHALF + lane_base;                 // A half image wm, block t at oa ^ (32 t)
+  const unsigned ob = lds0 + (2 + (wn >> 1)) * BHALF + lane_base;    // B half image, blocks 4 (wn & 1) + u
+  const unsigned bblk0 = 4 * (wn & 1);
+  // LDS-DMA: wave w fills image (w >> 1), token rows 16 (w & 1) + 4 u + (lane >> 4), u = 0..3
+  const int img = wave >> 1;
+  const int rl = lane >> 4;
+  const int chunk_lo = (lane & 15) ^ (rl << 2);               // pieces 0, 1 (token-row bit 3 clear)
+  const int chunk_hi = chunk_lo ^ 2;                          // pieces 2, 3
+  const int dma_dst = img * BHALF + (16 * (wave & 1)) * 256;
+
+  const int bid = blockIdx.x;
+  int run_begin = 0, run_end = 0;
+  const bool whole = bid < plan.dp_tiles;
+  if (!whole) {
+    run_begin = (bid - plan.dp_tiles) * plan.chunk;
+    run_end = min(run_begin + plan.chunk, plan.left_tiles * nk_all);
+  }
+  for (int seg = 0; seg < 2; ++seg) {
+    int tile, s0, s1;
+    if (whole) {
+      if (seg == 1) break;
+      tile = bid; s0 = 0; s1 = nk_all;
+    } else {
+      const int l = run_begin / nk_all + seg;
+      s0 = seg == 0 ? run_begin - l * nk_all : 0;
+      s1 = min(run_end - l * nk_all, nk_all);
+      if (s1 <= s0) break;
+      tile = plan.dp_tiles + l;
+    }
+    const int prob = tile / plan.tiles_per_prob;
+    const XList& xl = pg.x[prob];
+    int ti, tj;
+    hessian_tile_of(tile - prob * plan.tiles_per_prob, C / BT, ti, tj);
+    const int nk = s1 - s0;
+
+    const long gcol = (img < 2 ? (long)ti * BT : (long)tj * BT) + (img & 1) * 128;
+    const long lane_goff = (long)(16 * (wave & 1) + rl) * ldx + gcol + 8 * chunk_lo;
+    const long hi_delta = 8 * (chunk_hi - chunk_lo);
+    int is_slab = s0 / spk, is_in = s0 - is_slab * spk, is_st = 0;
+    const unsigned short* src = xl.p[is_slab] + lane_goff + (long)is_in * BBK * ldx;
+    auto piece = [&](int u) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (long)(4 * u) * ldx + (u >= 2 ? hi_delta : 0)),
+                                       (__attribute__((address_space(3))) void*)(ring + (is_st % BRING) * BSTAGE + dma_dst + u * 1024),
+                                       16, 0, 0);
+    };
+    auto advance = [&]() {
+      ++is_st;
+      if (is_st < nk) {
+        if (++is_in == spk) {
+          is_in = 0;
+          ++is_slab;
+          src = xl.p[is_slab] + lane_goff;
+        } else {
+          src += (long)BBK * ldx;
+        }
+      }
+    };
+
+    f32x4v acc[8][4];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[t][u][e] = 0.f;
+
+#pragma unroll
+    for (int st = 0; st < BRING - 1; ++st) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) piece(u);
+      advance();
+    }
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) piece(u);
+    advance();
+
+    frag_t fl[8], fh[8], fbA[8], fbB[8];                        // A blocks 0-3 / 4-7, B (two sets, alternating by stage)
+    {
+      const unsigned abase = oa, bbase = ob;
+      B16_RA(fl, 0, 0); B16_RA(fl, 1, 1); B16_RA(fl, 2, 2); B16_RA(fl, 3, 3);
+      B16_RB(fbA, 0); B16_RB(fbA, 1); B16_RB(fbA, 2); B16_RB(fbA, 3);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    BSB;
+#define B16_STAGE(KT, FB_CUR, FB_NEXT)                                                                      \
+    {                                                                                                       \
+      {                                                                                                     \
+        const unsigned abase = oa + ((KT) % BRING) * BSTAGE;                                                \
+        /* P1: gap k < 4 reads A block 4 + k of this stage */                                               \
+        _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) {                                                  \
+          const s16x8 fa_ = join8(fl[2 * t_], fl[2 * t_ + 1]);                                              \
+          _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                                                \
+            const s16x8 fb_ = join8(FB_CUR[2 * u_], FB_CUR[2 * u_ + 1]);                                    \
+            acc[t_][u_] = mfma16s<BF16>(fa_, fb_, acc[t_][u_]);                                             \
+            BSB;                                                                                            \
+            if (t_ == 0) B16_RA(fh, u_, 4 + u_);                                                            \
+            BSB;                                                                                            \
+          }                                                                                                 \
+        }                                                                                                   \
+      }                                                                                                     \
+      BSB;                                                                                                  \
+      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                                           \
+      __builtin_amdgcn_s_barrier();                                                                         \
+      BSB;                                                                                                  \
+      {                                                                                                     \
+        const unsigned abase = oa + (((KT) + 1) % BRING) * BSTAGE, bbase = ob + (((KT) + 1) % BRING) * BSTAGE; \
+        /* P2: gaps 0-3 read the next stage's A blocks 0-3, gaps 4-7 its B blocks, gaps 8-11 carry the DMA */ \
+        _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) {                                                  \
+          const s16x8 fa_ = join8(fh[2 * t_], fh[2 * t_ + 1]);                                              \
+          _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                                                \
+            const s16x8 fb_ = join8(FB_CUR[2 * u_], FB_CUR[2 * u_ + 1]);                                    \
+            acc[4 + t_][u_] = mfma16s<BF16>(fa_, fb_, acc[4 + t_][u_]);                                     \
+            BSB;                                                                                            \
+            if (t_ == 0) B16_RA(fl, u_, u_);                                                                \
+            if (t_ == 1) B16_RB(FB_NEXT, u_);                                                               \
+            if (t_ == 2) piece(u_);                                                                         \
+            BSB;                                                                                            \
+          }                                                                                                 \
+        }                                                                                                   \
+      }                                                                                                     \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
+      BSB;                                                                                                  \
+      advance();                                                                                            \
+    }
+    for (int kt = 0; kt < nk; kt += 2) {
+      B16_STAGE(kt, fbA, fbB);
+      B16_STAGE(kt + 1, fbB, fbA);
+    }
+#undef B16_STAGE
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    BSB;
+    __builtin_amdgcn_s_barrier();
+
+    if (whole) {
+      float* __restrict__ H = pg.H[prob];
+      const float alpha = pg.alpha[prob], beta = pg.beta[prob];
+#pragma unroll
+      for (int t2 = 0; t2 < 4; ++t2) {
+        float v[2][4][4];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[tt][u][e] = acc[2 * t2 + tt][u][e];
+        big16_epilogue_rows(H, ldh, ti, tj, wm, wn, lane, t2, v, alpha, beta);
+      }
+    } else {
+      float* __restrict__ part = plan.ws + ((long)(bid - plan.dp_tiles) * 2 + seg) * BTILE_FLOATS;
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) part[big16_part_index(wave, t, u, e, lane)] = acc[t][u][e];
+    }
+  }
+}
+
+__global__ __launch_bounds__(512) void hessian16_big16_fixup(ProbGroup pg, BigPlan plan, int ldh, int C, int nk_all) {
+  const int l = blockIdx.x;
+  const int tile = plan.dp_tiles + l;
+  const int prob = tile / plan.tiles_per_prob;
+  int ti, tj;
+  hessian_tile_of(tile - prob * plan.tiles_per_prob, C / BT, ti, tj);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int first = l * nk_all, last = first + nk_all - 1;
+  const int w0 = first / plan.chunk, w1 = min(last / plan.chunk, plan.workers - 1);
+  float* __restrict__ H = pg.H[prob];
+  const float alpha = pg.alpha[prob], beta = pg.beta[prob];
+  const int t2 = blockIdx.y;
+  float v[2][4][4];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[tt][u][e] = 0.f;
+  for (int w = w0; w <= w1; ++w) {
+    const int seg = (w * plan.chunk < first) ? 1 : 0;
+    const float* __restrict__ part = plan.ws + ((long)w * 2 + seg) * BTILE_FLOATS;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[tt][u][e] += part[big16_part_index(wave, 2 * t2 + tt, u, e, lane)];
+  }
+  big16_epilogue_rows(H, ldh, ti, tj, wm, wn, lane, t2, v, alpha, beta);
+}
+
 // A[r][c] = A[c][r] for r > c, through a 32x33 LDS tile so both sides stay coalesced.
 __global__ __launch_bounds__(256) void symmetrize_kernel(float* __restrict__ A, int lda, int n) {
   __shared__ float t[32][33];
@@ -709,6 +973,8 @@ static int hessian_launch(const HostProb* probs, int n_prob, int ldh, int n_x, i
             for (int i = 0; i < nx; ++i) pg.x[p].p[i] = static_cast<const unsigned short*>(probs[p0 + p].xs[i0 + i]);
           }
           const int total = np * blocks256, nk_all = tokens / BBK * nx;
+          static const int shape_env = [] { const char* e = getenv("GPTQ_HESS_SHAPE"); return e ? atoi(e) : 32; }();
+          const bool shape16 = shape_env == 16 && nk_all % 2 == 0;
           BigPlan plan{blocks256, total, 0, 0, 1, nullptr};
           const int full = total / n_cu * n_cu, left = total - full;
           // cut the last round along K when it would run under 90 % full and a run still has >= 8 stages
@@ -717,6 +983,7 @@ static int hessian_launch(const HostProb* probs, int n_prob, int ldh, int n_x, i
             plan.left_tiles = left;
             plan.workers = n_cu;
             plan.chunk = cdiv((long)left * nk_all, n_cu);
+            if (shape16) plan.chunk += plan.chunk & 1;                  // the 16x16x32 kernel walks stages in pairs
             plan.workers = cdiv((long)left * nk_all, plan.chunk);
             plan.ws = static_cast<float*>(scratch_buffer(s, sizeof(float) * 2 * BTILE_FLOATS * (size_t)plan.workers));
             GPTQ_CHECK_ARG(plan.ws != nullptr, "gptq_hessian_accum: cannot allocate the %zu-byte split-K workspace",
@@ -732,6 +999,20 @@ static int hessian_launch(const HostProb* probs, int n_prob, int ldh, int n_x, i
   } while (0)
           static const int bring_env = [] { const char* e = getenv("GPTQ_HESS_RING"); return e ? atoi(e) : BRING_DEFAULT; }();
           static const int babl_env = [] { const char* e = getenv("GPTQ_HESS_ABLATE"); return e ? atoi(e) : 0; }();
+          if (shape16) {
+            const size_t lds_b = (size_t)BRING_DEFAULT * BSTAGE;
+            if (x_dtype == GPTQ_BF16) {
+              GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_big16_kernel<true>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+              hessian16_big16_kernel<true><<<grid, 512, lds_b, s>>>(pg, plan, ldh, nx, ldx, C, tokens);
+            } else {
+              GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_big16_kernel<false>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+              hessian16_big16_kernel<false><<<grid, 512, lds_b, s>>>(pg, plan, ldh, nx, ldx, C, tokens);
+            }
+            if (plan.left_tiles > 0) hessian16_big16_fixup<<<dim3(plan.left_tiles, 4), 512, 0, s>>>(pg, plan, ldh, C, nk_all);
+            continue;
+          }
           if (x_dtype == GPTQ_BF16) HBIG(true, BRING_DEFAULT, 0);
           else if (babl_env == 1) HBIG(false, BRING_DEFAULT, 1);
           else if (babl_env == 2) HBIG(false, BRING_DEFAULT, 2);

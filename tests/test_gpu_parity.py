@@ -769,3 +769,20 @@ def test_hessian_grouped_problems_single_launch(G, O, hip_device):
     finally:
         gmod.HESSIAN_DEFER = old
         gmod.FLUSH_EVENTS = None
+
+
+# ----------------------------------------------------------------- kernel variants selected by environment
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"GPTQ_HESS_BIG": "2", "GPTQ_HESS_SHAPE": "16"},     # 256x256 tiles on 16x16x32 MFMAs
+                                 {"GPTQ_HESS_BIG": "3"},                               # no K-split last round
+                                 {"GPTQ_HESS_BIG": "0"}])                              # 128x128 tiles only
+def test_hessian_kernel_variants_in_subprocess(env):
+    """The library reads its kernel-selection knobs once per process: exercise the non-default Hessian kernels
+    through tools/hessian_big_check.py (fp64 reference, several shapes incl. a K-split one) in a child process."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "hessian_big_check.py"), "--no-time"], env=e,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("rel err") == 4
