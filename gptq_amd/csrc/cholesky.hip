@@ -258,8 +258,11 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_v2_kernel(float* __restric
 #pragma unroll
       for (int j = 0; j < 32; ++j) {
         const float ajj = lane_bcast(a[j], j);
-        const float d = sqrtf(ajj);
-        const float inv = 1.f / d;
+        // 1/sqrt by v_rsq_f32 + one Newton step, l_jj = a_jj * that: the IEEE sqrt + division pair costs ~160 more
+        // cycles on this 128-step serial chain; the factor stays within ~1 ulp (tolerance-level, like the rest)
+        float inv = __builtin_amdgcn_rsqf(ajj);
+        inv = inv * (1.5f - 0.5f * ajj * inv * inv);
+        const float d = ajj * inv;
         if (lane == 0) {
           rd[o + j] = inv;
           if (!(ajj > 0.f) && info) atomicCAS(info, 0, kb * NB + o + j + 1);
@@ -312,11 +315,7 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_v2_kernel(float* __restric
     }
     __syncthreads();
   }
-  // L_kk back to A (kept for inspection)
-  for (int idx = tid; idx < NB * NB; idx += 512) {
-    const int i = idx >> 7, k = idx & 127;
-    if (k <= i) Ak[(long)i * Cp + k] = S[i * LD + k];
-  }
+  // (L_kk is not written back: the panel solve and the triangular inverse only read its inverse from Linv)
 
   // ---------------------------------- inverse ----------------------------------
   if (abl & 8) return;

@@ -118,6 +118,7 @@ def flush_pending():
 
 
 _SOLVE_STREAMS = {}   # device -> pool of streams for fasterquant_many
+LANE_EVENTS = None    # set to a list to collect (lane, start_event, end_event, host_enqueue_seconds) per fasterquant_many lane
 SOLVE_STREAMS = 3     # concurrent solves per device: the caller's stream (it carries the largest solve and owns the
                       # library's look-ahead helper stream) + 2 more = the 4 hardware queues HIP uses by default;
                       # streams beyond the queues serialize falsely
@@ -158,14 +159,25 @@ def fasterquant_many(solvers, blocksize=128, percdamp=.01, groupsize=-1, actorde
             used, mine = lanes[1:], []
             for st in used:                          # before anything of this call lands on `cur`:
                 st.wait_stream(cur)                  # H, layer.weight were produced on the caller's stream
+            if LANE_EVENTS is not None:
+                lane_ev = [[torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), 0.0] for _ in lanes]
+                for st, le in zip(lanes, lane_ev):
+                    le[0].record(st)
             for g in order:
                 k = min(range(want), key=lambda j: (load[j], j))
                 load[k] += cost(g)
                 st = lanes[k]
                 if st is not cur and g._H is not None:
                     g._H.record_stream(st)
+                t_host = time.perf_counter()
                 with torch.cuda.stream(st):
                     mine.append((g, g._solve_enqueue(blocksize, percdamp, groupsize, actorder, static_groups)))
+                if LANE_EVENTS is not None:
+                    lane_ev[k][2] += time.perf_counter() - t_host
+            if LANE_EVENTS is not None:
+                for j, (st, le) in enumerate(zip(lanes, lane_ev)):
+                    le[1].record(st)
+                    LANE_EVENTS.append((j, le[0], le[1], le[2]))
             for st in used:
                 cur.wait_stream(st)                  # everything after this call sees the results
             for g, state in mine:
