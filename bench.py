@@ -228,24 +228,25 @@ def main():
         # roofline of the dominant kernel AT its dominant launch shape: the Hessian of the widest Linear
         # (fc2, C = 8192), `hessian_defer` samples of 2048 tokens per launch.  Algorithmic flops per
         # launch = samples * S * C^2 (the symmetric half actually needed); duration = HIP events around
-        # that Linear's launch sequence / number of launches (rocprofv3 summary under profiles/ agrees).
+        # each such launch (rocprofv3 summary under profiles/ agrees).
         ub = units[big]
         per_launch = max(1, args.hessian_defer)
-        # executed algorithmic flops: S*C^2 (upper-triangle SYRK) per problem and slab of every Hessian launch
-        hess_flops = sum(nprob * nslab * float(SEQLEN) * C_ * C_ for (C_, nprob, nslab, a, b) in flush_events)
-        durs = [a.elapsed_time(b) for (C_, nprob, nslab, a, b) in flush_events if C_ == ub.cols and nslab == per_launch]
-        n_launch = len(durs)
-        launch_ms = sum(durs) / max(n_launch, 1)
-        flops_launch = per_launch * float(SEQLEN) * ub.cols * ub.cols
+        # executed algorithmic flops: S*C^2 (upper-triangle SYRK) per problem and slab of every Hessian launch.
+        hess_flops = sum(nslab * float(SEQLEN) * sum(float(c) * c for c in Cs) for (Cs, nslab, a, b) in flush_events)
+        sel = [(Cs, a.elapsed_time(b)) for (Cs, nslab, a, b) in flush_events if max(Cs) == ub.cols and nslab == per_launch]
+        n_launch = len(sel)
+        launch_ms = sum(d for _, d in sel) / max(n_launch, 1)
+        shape_cs = sel[0][0] if sel else [ub.cols]
+        flops_launch = per_launch * float(SEQLEN) * sum(float(c) * c for c in shape_cs)
         achieved = flops_launch / (launch_ms / 1e3) / 1e12 if launch_ms > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_hessian16_big_pmc.json")   # tools/pmc_traffic.py, same launch shape
-        if os.path.exists(pmc) and ub.cols == 8192 and per_launch == 8:
+        if os.path.exists(pmc) and shape_cs == [8192] and per_launch == 8:
             traffic = json.load(open(pmc))["hbm_bytes_per_launch"]      # FETCH_SIZE x2 (gfx950) + WRITE_SIZE
         out["roofline"] = {
             "kernel": "hessian16_big_kernel<f16> + hessian16_big_fixup (v_mfma_f32_32x32x16_f16 SYRK, 256x256 upper-triangle "
                       "tiles, K-split last round, fp32 accumulate)",
-            "launch_shape": f"C={ub.cols}, {per_launch} samples x {SEQLEN} tokens per launch", "bound": "mfma",
+            "launch_shape": f"Hessians of C = {sorted(shape_cs, reverse=True)} in one launch, {per_launch} samples x {SEQLEN} tokens each", "bound": "mfma",
             "achieved": round(achieved, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4), "traffic": traffic,
             "algorithmic_flops_per_launch": flops_launch, "avg_launch_ms": round(launch_ms, 4), "launches": n_launch,

@@ -214,7 +214,17 @@ struct XList { const unsigned short* p[MAX_XLIST]; };   // up to 16 equally shap
 constexpr int MAX_PROB = 8;
 // several independent (H, slabs) problems of identical shape in ONE launch: the Linears of a block that
 // share in_features (q,k,v,out,fc1 ...) each bring only C/128*(C/128+1)/2 tiles, too few to fill 256 CUs alone
-struct ProbGroup { float* H[MAX_PROB]; XList x[MAX_PROB]; float alpha[MAX_PROB]; float beta[MAX_PROB]; };
+struct ProbGroup {
+  float* H[MAX_PROB]; XList x[MAX_PROB]; float alpha[MAX_PROB]; float beta[MAX_PROB];
+  // the 256 x 256 kernels also take problems of DIFFERENT width in one launch (fc2 together with q/k/v/out/fc1 of
+  // the block): per-problem C, leading dimensions and the first tile id of each problem
+  int C[MAX_PROB]; int ldx[MAX_PROB]; int ldh[MAX_PROB]; int tile_start[MAX_PROB + 1]; int n_prob;
+};
+__device__ __forceinline__ int prob_of_tile(const ProbGroup& pg, int tile) {
+  int p = 0;
+  while (p + 1 < pg.n_prob && tile >= pg.tile_start[p + 1]) ++p;
+  return p;
+}
 constexpr int DSTAGE = 2 * HBK * 256;        // bytes per ring slot: A + B, 64 rows x 256 B each
 
 __device__ __forceinline__ void dma_stage(const unsigned short* __restrict__ Xa, const unsigned short* __restrict__ Xb,
@@ -422,7 +432,6 @@ constexpr int BRING_DEFAULT = 4;
 // never longer than one tile's K -- write their fp32 partial tiles to a workspace, and hessian16_big_fixup
 // adds the partials of a tile in run order (fixed order: results do not depend on timing) and applies the epilogue.
 struct BigPlan {
-  int tiles_per_prob;   // 256 x 256 upper-triangle tiles of one problem
   int dp_tiles;         // tiles done whole by workgroups [0, dp_tiles)
   int left_tiles;       // tiles cut along K
   int workers;          // workgroups [dp_tiles, dp_tiles + workers)
@@ -465,8 +474,7 @@ __device__ __forceinline__ void big_epilogue_rows(float* __restrict__ H, int ldh
 
 // ABL (diagnostic builds only): 1 = no fragment reads / MFMAs, 2 = no LDS-DMA.
 template <bool BF16, int BRING = BRING_DEFAULT, int ABL = 0>
-__global__ __launch_bounds__(512) void hessian16_big_kernel(ProbGroup pg, BigPlan plan, int ldh, int nx,
-                                                            int ldx, int C, int tokens) {
+__global__ __launch_bounds__(512) void hessian16_big_kernel(ProbGroup pg, BigPlan plan, int nx, int tokens) {
   extern __shared__ __attribute__((aligned(1024))) char ring[];          // BRING x BSTAGE, the ONLY LDS object
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -509,10 +517,11 @@ __global__ __launch_bounds__(512) void hessian16_big_kernel(ProbGroup pg, BigPla
       if (s1 <= s0) break;
       tile = plan.dp_tiles + l;
     }
-    const int prob = tile / plan.tiles_per_prob;
+    const int prob = prob_of_tile(pg, tile);
     const XList& xl = pg.x[prob];
+    const int ldx = pg.ldx[prob], ldh = pg.ldh[prob];
     int ti, tj;
-    hessian_tile_of(tile - prob * plan.tiles_per_prob, C / BT, ti, tj);
+    hessian_tile_of(tile - pg.tile_start[prob], pg.C[prob] / BT, ti, tj);
     const int nk = s1 - s0;
 
     const long gcol = (img < 2 ? (long)ti * BT : (long)tj * BT) + (img & 1) * 128;
@@ -623,12 +632,13 @@ __global__ __launch_bounds__(512) void hessian16_big_kernel(ProbGroup pg, BigPla
 }
 
 // Four workgroups per K-split tile: sum its partial tiles in run order, then the usual epilogue.
-__global__ __launch_bounds__(512) void hessian16_big_fixup(ProbGroup pg, BigPlan plan, int ldh, int C, int nk_all) {
+__global__ __launch_bounds__(512) void hessian16_big_fixup(ProbGroup pg, BigPlan plan, int nk_all) {
   const int l = blockIdx.x;
   const int tile = plan.dp_tiles + l;
-  const int prob = tile / plan.tiles_per_prob;
+  const int prob = prob_of_tile(pg, tile);
+  const int ldh = pg.ldh[prob];
   int ti, tj;
-  hessian_tile_of(tile - prob * plan.tiles_per_prob, C / BT, ti, tj);
+  hessian_tile_of(tile - pg.tile_start[prob], pg.C[prob] / BT, ti, tj);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 2, wn = wave & 3;
   const int first = l * nk_all, last = first + nk_all - 1;
@@ -710,8 +720,7 @@ __device__ __forceinline__ void big16_epilogue_rows(float* __restrict__ H, int l
 #define B16_RA(FA, T, TBLK) do { const unsigned ad_ = abase ^ (32u * (TBLK)); TR_READ(FA[2 * (T)], ad_, 0); TR_READ(FA[2 * (T) + 1], ad_, 1024); } while (0)
 #define B16_RB(FB, U) do { const unsigned ad_ = bbase ^ (32u * (bblk0 + (U))); TR_READ(FB[2 * (U)], ad_, 0); TR_READ(FB[2 * (U) + 1], ad_, 1024); } while (0)
 template <bool BF16>
-__global__ __launch_bounds__(512) void hessian16_big16_kernel(ProbGroup pg, BigPlan plan, int ldh, int nx,
-                                                              int ldx, int C, int tokens) {
+__global__ __launch_bounds__(512) void hessian16_big16_kernel(ProbGroup pg, BigPlan plan, int nx, int tokens) {
   constexpr int BRING = BRING_DEFAULT;
   extern __shared__ __attribute__((aligned(1024))) char ring[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -753,10 +762,11 @@ __global__ __launch_bounds__(512) void hessian16_big16_kernel(ProbGroup pg, BigP
       if (s1 <= s0) break;
       tile = plan.dp_tiles + l;
     }
-    const int prob = tile / plan.tiles_per_prob;
+    const int prob = prob_of_tile(pg, tile);
     const XList& xl = pg.x[prob];
+    const int ldx = pg.ldx[prob], ldh = pg.ldh[prob];
     int ti, tj;
-    hessian_tile_of(tile - prob * plan.tiles_per_prob, C / BT, ti, tj);
+    hessian_tile_of(tile - pg.tile_start[prob], pg.C[prob] / BT, ti, tj);
     const int nk = s1 - s0;
 
     const long gcol = (img < 2 ? (long)ti * BT : (long)tj * BT) + (img & 1) * 128;
@@ -885,12 +895,13 @@ __global__ __launch_bounds__(512) void hessian16_big16_kernel(ProbGroup pg, BigP
   }
 }
 
-__global__ __launch_bounds__(512) void hessian16_big16_fixup(ProbGroup pg, BigPlan plan, int ldh, int C, int nk_all) {
+__global__ __launch_bounds__(512) void hessian16_big16_fixup(ProbGroup pg, BigPlan plan, int nk_all) {
   const int l = blockIdx.x;
   const int tile = plan.dp_tiles + l;
-  const int prob = tile / plan.tiles_per_prob;
+  const int prob = prob_of_tile(pg, tile);
+  const int ldh = pg.ldh[prob];
   int ti, tj;
-  hessian_tile_of(tile - prob * plan.tiles_per_prob, C / BT, ti, tj);
+  hessian_tile_of(tile - pg.tile_start[prob], pg.C[prob] / BT, ti, tj);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 2, wn = wave & 3;
   const int first = l * nk_all, last = first + nk_all - 1;
@@ -942,89 +953,114 @@ __global__ __launch_bounds__(256) void symmetrize_kernel(float* __restrict__ A, 
 using namespace gptq;
 
 // One H update per problem; every problem brings `n_x` equally shaped slabs [tokens, C] (row-major, ldx).
-struct HostProb { float* H; const void* const* xs; float alpha, beta; };
+struct HostProb { float* H; const void* const* xs; float alpha, beta; int C, ldx, ldh; };
 
-static int hessian_launch(const HostProb* probs, int n_prob, int ldh, int n_x, int x_dtype, int ldx, int C,
-                          int tokens, hipStream_t s) {
+// GPTQ_HESS_BIG: 0 = 128 x 128 kernel only, 1 = default, 2 = 256 x 256 kernel whenever the shapes allow,
+//                3 = like 2 but without the K-split last round
+static int hess_big_env() {
+  static const int v = [] { const char* e = getenv("GPTQ_HESS_BIG"); return e ? atoi(e) : 1; }();
+  return v;
+}
+
+static bool big_eligible(const HostProb& pr, int n_x, int x_dtype, int tokens) {
+  if (x_dtype != GPTQ_F16 && x_dtype != GPTQ_BF16) return false;
+  if (pr.C % BT != 0 || pr.ldx % 8 != 0 || tokens % BBK != 0) return false;
+  for (int i = 0; i < n_x; ++i)
+    if (reinterpret_cast<uintptr_t>(pr.xs[i]) % 16 != 0) return false;
+  return true;
+}
+
+// 256 x 256 kernels: up to MAX_PROB problems per launch, of possibly different widths (all big_eligible).
+static int hessian_launch_big(const HostProb* probs, int n_prob, int n_x, int x_dtype, int tokens, hipStream_t s) {
+  const int big_env = hess_big_env();
+  int dev = 0, n_cu = 256;
+  GPTQ_CHECK_HIP(hipGetDevice(&dev));
+  GPTQ_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  for (int p0 = 0; p0 < n_prob; p0 += MAX_PROB) {
+    const int np = std::min(MAX_PROB, n_prob - p0);
+    for (int i0 = 0; i0 < n_x; i0 += MAX_XLIST) {
+      const int nx = std::min(MAX_XLIST, n_x - i0);
+      ProbGroup pg{};
+      pg.n_prob = np;
+      int total = 0;
+      for (int p = 0; p < np; ++p) {
+        const HostProb& pr = probs[p0 + p];
+        pg.H[p] = pr.H;
+        pg.alpha[p] = i0 == 0 ? pr.alpha : 1.f;
+        pg.beta[p] = pr.beta;
+        pg.C[p] = pr.C; pg.ldx[p] = pr.ldx; pg.ldh[p] = pr.ldh;
+        pg.tile_start[p] = total;
+        total += (pr.C / BT) * (pr.C / BT + 1) / 2;
+        for (int i = 0; i < nx; ++i) pg.x[p].p[i] = static_cast<const unsigned short*>(pr.xs[i0 + i]);
+      }
+      for (int p = np; p <= MAX_PROB; ++p) pg.tile_start[p] = total;
+      const int nk_all = tokens / BBK * nx;
+      static const int shape_env = [] { const char* e = getenv("GPTQ_HESS_SHAPE"); return e ? atoi(e) : 32; }();
+      const bool shape16 = shape_env == 16 && nk_all % 2 == 0;
+      BigPlan plan{total, 0, 0, 1, nullptr};   // dp_tiles, left_tiles, workers, chunk, ws
+      const int full = total / n_cu * n_cu, left = total - full;
+      // cut the last round along K when it would run under 90 % full and a run still has >= 8 stages
+      if (big_env != 3 && left > 0 && left * 10 < n_cu * 9 && (long)left * nk_all >= 8L * n_cu) {
+        plan.dp_tiles = full;
+        plan.left_tiles = left;
+        plan.chunk = cdiv((long)left * nk_all, n_cu);
+        if (shape16) plan.chunk += plan.chunk & 1;                  // the 16x16x32 kernel walks stages in pairs
+        plan.workers = cdiv((long)left * nk_all, plan.chunk);
+        plan.ws = static_cast<float*>(scratch_buffer(s, sizeof(float) * 2 * BTILE_FLOATS * (size_t)plan.workers));
+        GPTQ_CHECK_ARG(plan.ws != nullptr, "gptq_hessian_accum: cannot allocate the %zu-byte split-K workspace",
+                       sizeof(float) * 2 * BTILE_FLOATS * (size_t)plan.workers);
+      }
+      const int grid = plan.dp_tiles + plan.workers;
+#define HBIG(BF, RG, AB)                                                                                      \
+  do {                                                                                                        \
+    const size_t lds_b = (size_t)(RG) * BSTAGE;                                                               \
+    GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_big_kernel<BF, RG, AB>),      \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));              \
+    hessian16_big_kernel<BF, RG, AB><<<grid, 512, lds_b, s>>>(pg, plan, nx, tokens);                          \
+  } while (0)
+      static const int bring_env = [] { const char* e = getenv("GPTQ_HESS_RING"); return e ? atoi(e) : BRING_DEFAULT; }();
+      static const int babl_env = [] { const char* e = getenv("GPTQ_HESS_ABLATE"); return e ? atoi(e) : 0; }();
+      if (shape16) {
+        const size_t lds_b = (size_t)BRING_DEFAULT * BSTAGE;
+        if (x_dtype == GPTQ_BF16) {
+          GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_big16_kernel<true>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+          hessian16_big16_kernel<true><<<grid, 512, lds_b, s>>>(pg, plan, nx, tokens);
+        } else {
+          GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_big16_kernel<false>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+          hessian16_big16_kernel<false><<<grid, 512, lds_b, s>>>(pg, plan, nx, tokens);
+        }
+        if (plan.left_tiles > 0) hessian16_big16_fixup<<<dim3(plan.left_tiles, 4), 512, 0, s>>>(pg, plan, nk_all);
+        continue;
+      }
+      if (x_dtype == GPTQ_BF16) HBIG(true, BRING_DEFAULT, 0);
+      else if (babl_env == 1) HBIG(false, BRING_DEFAULT, 1);
+      else if (babl_env == 2) HBIG(false, BRING_DEFAULT, 2);
+      else if (bring_env == 5) HBIG(false, 5, 0);
+      else HBIG(false, BRING_DEFAULT, 0);
+#undef HBIG
+      if (plan.left_tiles > 0) hessian16_big_fixup<<<dim3(plan.left_tiles, 4), 512, 0, s>>>(pg, plan, nk_all);
+    }
+  }
+  GPTQ_CHECK_LAUNCH("hessian16_big_kernel");
+  return GPTQ_OK;
+}
+
+// Problems of one shape (C, ldx, ldh as in probs[0]).
+static int hessian_launch(const HostProb* probs, int n_prob, int n_x, int x_dtype, int tokens, hipStream_t s) {
+  const int C = probs[0].C, ldx = probs[0].ldx, ldh = probs[0].ldh;
   const int nt = cdiv(C, GBM);
   const int blocks = nt * (nt + 1) / 2;
   if (x_dtype == GPTQ_F16 || x_dtype == GPTQ_BF16) {
     bool aligned = (ldx % 8 == 0) && (tokens % HBK == 0) && (C % GBM == 0);
     for (int p = 0; p < n_prob; ++p)
       for (int i = 0; i < n_x; ++i) aligned = aligned && (reinterpret_cast<uintptr_t>(probs[p].xs[i]) % 16 == 0);
-    static const int big_env = [] { const char* e = getenv("GPTQ_HESS_BIG"); return e ? atoi(e) : 1; }();
-    // GPTQ_HESS_BIG: 0 = 128 x 128 kernel only, 1 = default, 2 = 256 x 256 kernel whenever the shape allows,
-    //                3 = like 2 but without the K-split last round
+    const int big_env = hess_big_env();
+    bool big_ok = big_env != 0;
+    for (int p = 0; p < n_prob; ++p) big_ok = big_ok && big_eligible(probs[p], n_x, x_dtype, tokens);
     const long big_tiles = (long)(C / BT) * (C / BT + 1) / 2 * n_prob;
-    if (aligned && big_env && C % BT == 0 && tokens % BBK == 0 && (big_env >= 2 || big_tiles >= 100)) {
-      const int blocks256 = (C / BT) * (C / BT + 1) / 2;
-      int dev = 0, n_cu = 256;
-      GPTQ_CHECK_HIP(hipGetDevice(&dev));
-      GPTQ_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-      for (int p0 = 0; p0 < n_prob; p0 += MAX_PROB) {
-        const int np = std::min(MAX_PROB, n_prob - p0);
-        for (int i0 = 0; i0 < n_x; i0 += MAX_XLIST) {
-          const int nx = std::min(MAX_XLIST, n_x - i0);
-          ProbGroup pg{};
-          for (int p = 0; p < np; ++p) {
-            pg.H[p] = probs[p0 + p].H;
-            pg.alpha[p] = i0 == 0 ? probs[p0 + p].alpha : 1.f;
-            pg.beta[p] = probs[p0 + p].beta;
-            for (int i = 0; i < nx; ++i) pg.x[p].p[i] = static_cast<const unsigned short*>(probs[p0 + p].xs[i0 + i]);
-          }
-          const int total = np * blocks256, nk_all = tokens / BBK * nx;
-          static const int shape_env = [] { const char* e = getenv("GPTQ_HESS_SHAPE"); return e ? atoi(e) : 32; }();
-          const bool shape16 = shape_env == 16 && nk_all % 2 == 0;
-          BigPlan plan{blocks256, total, 0, 0, 1, nullptr};
-          const int full = total / n_cu * n_cu, left = total - full;
-          // cut the last round along K when it would run under 90 % full and a run still has >= 8 stages
-          if (big_env != 3 && left > 0 && left * 10 < n_cu * 9 && (long)left * nk_all >= 8L * n_cu) {
-            plan.dp_tiles = full;
-            plan.left_tiles = left;
-            plan.workers = n_cu;
-            plan.chunk = cdiv((long)left * nk_all, n_cu);
-            if (shape16) plan.chunk += plan.chunk & 1;                  // the 16x16x32 kernel walks stages in pairs
-            plan.workers = cdiv((long)left * nk_all, plan.chunk);
-            plan.ws = static_cast<float*>(scratch_buffer(s, sizeof(float) * 2 * BTILE_FLOATS * (size_t)plan.workers));
-            GPTQ_CHECK_ARG(plan.ws != nullptr, "gptq_hessian_accum: cannot allocate the %zu-byte split-K workspace",
-                           sizeof(float) * 2 * BTILE_FLOATS * (size_t)plan.workers);
-          }
-          const int grid = plan.dp_tiles + plan.workers;
-#define HBIG(BF, RG, AB)                                                                                      \
-  do {                                                                                                        \
-    const size_t lds_b = (size_t)(RG) * BSTAGE;                                                               \
-    GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_big_kernel<BF, RG, AB>),      \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));              \
-    hessian16_big_kernel<BF, RG, AB><<<grid, 512, lds_b, s>>>(pg, plan, ldh, nx, ldx, C, tokens);             \
-  } while (0)
-          static const int bring_env = [] { const char* e = getenv("GPTQ_HESS_RING"); return e ? atoi(e) : BRING_DEFAULT; }();
-          static const int babl_env = [] { const char* e = getenv("GPTQ_HESS_ABLATE"); return e ? atoi(e) : 0; }();
-          if (shape16) {
-            const size_t lds_b = (size_t)BRING_DEFAULT * BSTAGE;
-            if (x_dtype == GPTQ_BF16) {
-              GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_big16_kernel<true>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
-              hessian16_big16_kernel<true><<<grid, 512, lds_b, s>>>(pg, plan, ldh, nx, ldx, C, tokens);
-            } else {
-              GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_big16_kernel<false>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
-              hessian16_big16_kernel<false><<<grid, 512, lds_b, s>>>(pg, plan, ldh, nx, ldx, C, tokens);
-            }
-            if (plan.left_tiles > 0) hessian16_big16_fixup<<<dim3(plan.left_tiles, 4), 512, 0, s>>>(pg, plan, ldh, C, nk_all);
-            continue;
-          }
-          if (x_dtype == GPTQ_BF16) HBIG(true, BRING_DEFAULT, 0);
-          else if (babl_env == 1) HBIG(false, BRING_DEFAULT, 1);
-          else if (babl_env == 2) HBIG(false, BRING_DEFAULT, 2);
-          else if (bring_env == 5) HBIG(false, 5, 0);
-          else HBIG(false, BRING_DEFAULT, 0);
-#undef HBIG
-          if (plan.left_tiles > 0) hessian16_big_fixup<<<dim3(plan.left_tiles, 4), 512, 0, s>>>(pg, plan, ldh, C, nk_all);
-        }
-      }
-      GPTQ_CHECK_LAUNCH("hessian16_big_kernel");
-      return GPTQ_OK;
-    }
+    if (big_ok && (big_env >= 2 || big_tiles >= 100)) return hessian_launch_big(probs, n_prob, n_x, x_dtype, tokens, s);
     if (aligned) {
       static const int ring_env = [] { const char* e = getenv("GPTQ_HESS_RING"); return e ? atoi(e) : RING_DEFAULT; }();
       const size_t lds = (size_t)ring_env * DSTAGE;
@@ -1105,9 +1141,59 @@ extern "C" int gptq_hessian_accum_group(int n_prob, float* const* H, int ldh, co
     const int n_after = nsamples_before[p] + batch_total;
     probs[p] = HostProb{H[p], X + (long)p * n_x,
                         (float)((double)nsamples_before[p] / (double)n_after),   // gptq.py:59
-                        (float)(2.0 / (double)n_after)};                         // gptq.py:62 squared
+                        (float)(2.0 / (double)n_after),                          // gptq.py:62 squared
+                        C, ldx, ldh};
   }
-  return hessian_launch(probs, n_prob, ldh, n_x, x_dtype, ldx, C, tokens_each, static_cast<hipStream_t>(stream));
+  return hessian_launch(probs, n_prob, n_x, x_dtype, tokens_each, static_cast<hipStream_t>(stream));
+}
+
+// Problems of different widths in one call (the Linears of a block hooked in the same forward passes): those the
+// 256 x 256 kernel takes (C % 256 == 0, 16-bit activations, aligned) share its launches -- their tiles fill the
+// chip together and share the K-split last round -- the others go out per shape.
+extern "C" int gptq_hessian_accum_mixed(int n_prob, float* const* H, const int* ldh, const void* const* X, int n_x,
+                                        int x_dtype, const int* ldx, const int* C, int tokens_each,
+                                        const int* nsamples_before, int batch_total, gptq_stream_t stream) {
+  GPTQ_CHECK_ARG(n_prob > 0 && n_prob <= 64 && H && ldh && X && ldx && C && nsamples_before && n_x > 0,
+                 "gptq_hessian_accum_mixed: bad arguments");
+  GPTQ_CHECK_ARG(tokens_each > 0 && batch_total > 0, "gptq_hessian_accum_mixed: bad sizes");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  HostProb big[64], rest[64];
+  int n_big = 0, n_rest = 0;
+  long big_tiles = 0;
+  for (int p = 0; p < n_prob; ++p) {
+    GPTQ_CHECK_ARG(H[p] != nullptr && nsamples_before[p] >= 0 && C[p] > 0 && ldh[p] >= C[p] && ldx[p] >= C[p],
+                   "gptq_hessian_accum_mixed: bad problem %d", p);
+    for (int i = 0; i < n_x; ++i) GPTQ_CHECK_ARG(X[(long)p * n_x + i] != nullptr, "gptq_hessian_accum_mixed: null slab");
+    const int n_after = nsamples_before[p] + batch_total;
+    const HostProb pr{H[p], X + (long)p * n_x, (float)((double)nsamples_before[p] / (double)n_after),
+                      (float)(2.0 / (double)n_after), C[p], ldx[p], ldh[p]};
+    if (hess_big_env() != 0 && big_eligible(pr, n_x, x_dtype, tokens_each)) {
+      big[n_big++] = pr;
+      big_tiles += (long)(C[p] / BT) * (C[p] / BT + 1) / 2;
+    } else {
+      rest[n_rest++] = pr;
+    }
+  }
+  if (n_big > 0 && !(hess_big_env() >= 2 || big_tiles >= 100)) {      // too few tiles for the big kernel
+    for (int p = 0; p < n_big; ++p) rest[n_rest++] = big[p];
+    n_big = 0;
+  }
+  if (n_big > 0)
+    if (int rc = hessian_launch_big(big, n_big, n_x, x_dtype, tokens_each, s)) return rc;
+  // the others: one call per shape
+  bool done[64] = {};
+  for (int p = 0; p < n_rest; ++p) {
+    if (done[p]) continue;
+    HostProb same[64];
+    int n = 0;
+    for (int q = p; q < n_rest; ++q)
+      if (!done[q] && rest[q].C == rest[p].C && rest[q].ldx == rest[p].ldx && rest[q].ldh == rest[p].ldh) {
+        same[n++] = rest[q];
+        done[q] = true;
+      }
+    if (int rc = hessian_launch(same, n, n_x, x_dtype, tokens_each, s)) return rc;
+  }
+  return GPTQ_OK;
 }
 
 extern "C" int gptq_hessian_accum_multi(float* H, int ldh, const void* const* X, int n_x, int x_dtype, int ldx,

@@ -41,7 +41,7 @@ HESSIAN_DEFER = 1
 EMPTY_CACHE_ON_FREE = False
 
 _DIRTY = {}     # id -> GPTQ objects holding deferred hook inputs
-FLUSH_EVENTS = None   # set to a list to collect (C, n_problems, n_slabs, start_event, end_event) per Hessian launch
+FLUSH_EVENTS = None   # set to a list to collect ([C per problem], n_slabs, start_event, end_event) per Hessian call
 
 
 # Linears that are fed the SAME input tensor from the same forward passes (q/k/v, gate/up) accumulate the same
@@ -51,6 +51,10 @@ FLUSH_EVENTS = None   # set to a list to collect (C, n_problems, n_slabs, start_
 # copy it when they need their own (solve, `.H`, diverging inputs).  What every object ends up with is bit for bit
 # what it would have computed alone -- the kernel, its inputs and the order of the updates are the same.
 SHARE_INPUT_HESSIANS = True
+# Put Linears of different in_features into the same Hessian launches.  Measured neutral on the OPT-1.3b block
+# (1.31 ms for fc2 + the three C = 2048 Hessians together vs 1.06 + 0.27 ms apart: the larger K-split last round
+# eats what the shared launch saves), so launches stay per width by default.
+MIX_WIDTHS = False
 
 
 def _input_signature(o):
@@ -90,27 +94,35 @@ def flush_pending():
     for o in objs:
         o._fresh = False
     work = [o for o in objs if o._leader is None]
+    # one library call per (device, slab shape, batch structure[, width]); with MIX_WIDTHS the Linears of all widths
+    # go into the same call (gptq_hessian_accum_mixed then puts every width the 256x256-tile kernel takes into the
+    # same launches)
     groups = {}
     for o in work:
         x0 = o._pending[0][0]
-        key = (o.dev, o.columns, x0.shape[0], x0.dtype, x0.stride(0), len(o._pending),
-               sum(b for _, b in o._pending), o._H.stride(0))
+        key = (o.dev, x0.shape[0], x0.dtype, len(o._pending), sum(b for _, b in o._pending),
+               None if MIX_WIDTHS else o.columns)
         groups.setdefault(key, []).append(o)
-    for (dev, C, tokens, dtype, ldx, n_x, batch, ldh), members in groups.items():
+    for (dev, tokens, dtype, n_x, batch, _), members in groups.items():
+        members.sort(key=lambda o: -o.columns)         # widest first: its tiles lead the launch
         for i in range(0, len(members), 64):
             chunk = members[i:i + 64]
-            Hs = (ctypes.c_void_p * len(chunk))(*[o._H.data_ptr() for o in chunk])
-            Xs = (ctypes.c_void_p * (len(chunk) * n_x))(*[x.data_ptr() for o in chunk for x, _ in o._pending])
-            nb = (ctypes.c_int * len(chunk))(*[int(o._applied) for o in chunk])
+            n = len(chunk)
+            Hs = (ctypes.c_void_p * n)(*[o._H.data_ptr() for o in chunk])
+            Xs = (ctypes.c_void_p * (n * n_x))(*[x.data_ptr() for o in chunk for x, _ in o._pending])
+            nb = (ctypes.c_int * n)(*[int(o._applied) for o in chunk])
+            ldh = (ctypes.c_int * n)(*[o._H.stride(0) for o in chunk])
+            ldx = (ctypes.c_int * n)(*[o._pending[0][0].stride(0) for o in chunk])
+            Cs = (ctypes.c_int * n)(*[o.columns for o in chunk])
             with torch.cuda.device(dev):
                 if FLUSH_EVENTS is not None:
                     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     ev0.record()
-                _lib.call("gptq_hessian_accum_group", len(chunk), Hs, ldh, Xs, n_x, _lib._DTYPES[dtype], ldx, C,
-                          tokens, nb, int(batch), _lib.stream(dev))
+                _lib.call("gptq_hessian_accum_mixed", n, Hs, ldh, Xs, n_x, _lib._DTYPES[dtype], ldx, Cs, tokens, nb,
+                          int(batch), _lib.stream(dev))
                 if FLUSH_EVENTS is not None:
                     ev1.record()
-                    FLUSH_EVENTS.append((C, len(chunk), n_x, ev0, ev1))
+                    FLUSH_EVENTS.append(([o.columns for o in chunk], n_x, ev0, ev1))
     for o in objs:
         o._applied += sum(b for _, b in o._pending)
         o._pending = []

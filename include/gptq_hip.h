@@ -64,6 +64,15 @@ int gptq_hessian_accum_group(int n_prob, float* const* H, int ldh, const void* c
                              int x_dtype, int ldx, int C, int tokens_each, const int* nsamples_before,
                              int batch_total, gptq_stream_t stream);
 
+/* Several independent problems of DIFFERENT widths in one call: every Linear of a transformer block hooked in the
+ * same forward passes (GPTQ.add_batch, gptq.py:38-65, once per Linear and sample in the reference).  ldh, ldx, C,
+ * nsamples_before: host arrays [n_prob]; H, X as in gptq_hessian_accum_group; all problems bring n_x slabs of
+ * tokens_each rows.  Problems the 256x256-tile kernel accepts (16-bit activations, C % 256 == 0, 16-byte aligned
+ * rows) share its launches, so their tiles fill the chip together; the others are dispatched per shape. */
+int gptq_hessian_accum_mixed(int n_prob, float* const* H, const int* ldh, const void* const* X, int n_x,
+                             int x_dtype, const int* ldx, const int* C, int tokens_each,
+                             const int* nsamples_before, int batch_total, gptq_stream_t stream);
+
 /* Mirror the upper triangle of A [n, n] into the lower triangle. */
 int gptq_symmetrize(float* A, int lda, int n, gptq_stream_t stream);
 

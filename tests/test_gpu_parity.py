@@ -765,10 +765,36 @@ def test_hessian_grouped_problems_single_launch(G, O, hip_device):
         for k, g in enumerate(solvers):
             assert relfro(g.H.cpu(), refs[k]) <= 1e-6
         assert relfro(other.H.cpu(), ref_o) <= 1e-6
-        assert any(nprob == 3 and c == C for (c, nprob, nslab, _, _) in launches)   # the three went out together
+        assert any(cs == [C, C, C] for (cs, nslab, _, _) in launches)   # the three went out together
     finally:
         gmod.HESSIAN_DEFER = old
         gmod.FLUSH_EVENTS = None
+
+
+def test_hessians_of_different_widths_in_one_flush(G):
+    """Linears of different in_features hooked in the same forward passes go out in one library call
+    (gptq_hessian_accum_mixed): every H must match fp64, whichever kernel its width selects."""
+    gm = G.gptq
+    old = (gm.HESSIAN_DEFER, gm.SHARE_INPUT_HESSIANS, gm.MIX_WIDTHS)
+    gm.HESSIAN_DEFER, gm.MIX_WIDTHS = 3, True
+    try:
+        g2 = torch.Generator().manual_seed(11)
+        widths = [1024, 512, 320, 768, 512]                  # 320: not a multiple of 256 (128x128 / ragged kernels)
+        objs, xs = [], []
+        for C in widths:
+            gp = G.GPTQ(make_linear((torch.randn(8, C, generator=g2) * 0.02).half().cuda()))
+            objs.append(gp)
+            xs.append([(torch.randn(1, 96, C, generator=g2) * (1 + torch.arange(C) % 5)).half().cuda() for _ in range(5)])
+        for k in range(5):
+            for gp, x in zip(objs, xs):
+                gp.add_batch(x[k], None)
+        for gp, x in zip(objs, xs):
+            X = torch.cat([t[0] for t in x], 0).double()
+            ref = (2.0 / 5.0) * (X.t() @ X)
+            assert relfro(gp.H.double().cpu(), ref.cpu()) < 2e-6
+            assert torch.equal(gp.H, gp.H.t())
+    finally:
+        gm.HESSIAN_DEFER, gm.SHARE_INPUT_HESSIANS, gm.MIX_WIDTHS = old
 
 
 # ----------------------------------------------------------------- kernel variants selected by environment
@@ -785,4 +811,4 @@ def test_hessian_kernel_variants_in_subprocess(env):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "hessian_big_check.py"), "--no-time"], env=e,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("rel err") == 4
+    assert r.stdout.count("rel err") == 6

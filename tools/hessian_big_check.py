@@ -47,6 +47,57 @@ def check(C, tokens, n_x, n_prob, dtype):
     return Hs
 
 
+def accum_mixed(Hs, Xs, nb, batch):
+    n_x = len(Xs[0])
+    n = len(Hs)
+    Hp = (ctypes.c_void_p * n)(*[h.data_ptr() for h in Hs])
+    Xp = (ctypes.c_void_p * (n * n_x))(*[x.data_ptr() for xs in Xs for x in xs])
+    nbp = (ctypes.c_int * n)(*nb)
+    ldh = (ctypes.c_int * n)(*[h.stride(0) for h in Hs])
+    ldx = (ctypes.c_int * n)(*[xs[0].stride(0) for xs in Xs])
+    Cs = (ctypes.c_int * n)(*[h.shape[0] for h in Hs])
+    x0 = Xs[0][0]
+    _lib.call("gptq_hessian_accum_mixed", n, Hp, ldh, Xp, n_x, _lib._DTYPES[x0.dtype], ldx, Cs, x0.shape[0], nbp, batch,
+              _lib.stream(dev))
+
+
+def check_mixed(widths, tokens, n_x, dtype):
+    g = torch.Generator(device=dev).manual_seed(sum(widths) + tokens)
+    Xs = [[(torch.randn(tokens, C, device=dev, generator=g) * (1 + torch.arange(C, device=dev) % 7)).to(dtype)
+           for _ in range(n_x)] for C in widths]
+    Hs = [torch.randn(C, C, device=dev, generator=g) for C in widths]
+    H0 = [h.clone() for h in Hs]
+    nb = [2 + p for p in range(len(widths))]
+    accum_mixed(Hs, Xs, nb, n_x)
+    torch.cuda.synchronize()
+    worst = 0.0
+    for p, C in enumerate(widths):
+        X = torch.cat(Xs[p], 0).double()
+        n_after = nb[p] + n_x
+        ref = H0[p].double() * (nb[p] / n_after) + (2.0 / n_after) * (X.t() @ X)
+        up = torch.triu(torch.ones(C, C, device=dev, dtype=torch.bool))
+        worst = max(worst, ((Hs[p].double() - ref)[up].norm() / ref[up].norm()).item())
+        assert torch.equal(Hs[p][~up], H0[p][~up]), "strict lower triangle was written"
+    print(f"check mixed widths={widths} tokens={tokens} slabs={n_x} {dtype}: rel err {worst:.2e}", flush=True)
+    assert worst < 2e-6
+
+
+def timeit_mixed(widths, n_x=8, tokens=2048, reps=5):
+    Xs = [[torch.randn(tokens, C, device=dev, dtype=torch.float16) for _ in range(n_x)] for C in widths]
+    Hs = [torch.zeros(C, C, device=dev) for C in widths]
+    accum_mixed(Hs, Xs, [0] * len(widths), n_x)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for r in range(reps):
+        accum_mixed(Hs, Xs, [n_x * (r + 1)] * len(widths), n_x)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    print(f"time mixed widths={widths} slabs={n_x}x{tokens}: {ms * 1e3:.1f} us/launch, "
+          f"{n_x * tokens * sum(c * c for c in widths) / ms / 1e9:.1f} TFLOP/s algorithmic", flush=True)
+
+
 def timeit(C, n_prob, n_x=8, tokens=2048, reps=5):
     Xs = [[torch.randn(tokens, C, device=dev, dtype=torch.float16) for _ in range(n_x)] for _ in range(n_prob)]
     Hs = [torch.zeros(C, C, device=dev) for _ in range(n_prob)]
@@ -77,7 +128,10 @@ if "--dump" in args:
 check(4352, 64, 2, 1, torch.float16)       # 153 tiles of 256: the default heuristic takes the big kernel
 check(3072, 160, 1, 2, torch.bfloat16)
 check(512, 32, 5, 3, torch.float16)
+check_mixed([2304, 1024, 512, 320, 768], 96, 2, torch.float16)      # 320 takes the 128x128 / ragged kernels
+check_mixed([4352, 256, 256], 64, 3, torch.bfloat16)
 if "--no-time" not in args:
+    timeit_mixed([8192, 2048, 2048, 2048])
     timeit(8192, 1)
     timeit(2048, 5)
     timeit(4096, 1)
