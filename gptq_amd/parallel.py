@@ -18,10 +18,15 @@ import torch.distributed as dist
 
 @dataclass(frozen=True)
 class Unit:
-    """One Linear to quantize: `name`, out_features R, in_features C."""
+    """One Linear to quantize -- or a ROW SLAB of one: `name`, rows R (of the slab), in_features C, and the slab's
+    first row in the Linear (`row0`; `full_rows` = the Linear's out_features, 0 when the unit is the whole Linear).
+    Rows of W are independent problems given H (per-row grids, per-row error feedback, gptq.py:262-276), so a slab
+    is solved exactly like a Linear with fewer outputs; its owner needs the full Hessian."""
     name: str
     rows: int
     cols: int
+    row0: int = 0
+    full_rows: int = 0
 
     @property
     def params(self) -> int:
@@ -33,6 +38,38 @@ def unit_cost(u: Unit, nsamples: int, seqlen: int, blocksize: int = 128) -> floa
     + factorization chain (2/3 C^3 here) + trailing updates (R C^2) + in-block rank-1 updates."""
     R, C = u.rows, u.cols
     return nsamples * seqlen * C * C + (2.0 / 3.0) * C ** 3 + R * C * C + R * C * blocksize
+
+
+def split_rows(u: Unit, k: int, align: int = 128) -> List[Unit]:
+    """`u` as k row slabs of (nearly) equal height, boundaries on multiples of `align` (fewer slabs if R is small)."""
+    blocks = max(1, -(-u.rows // align))
+    k = max(1, min(k, blocks))
+    out, start = [], 0
+    for j in range(k):
+        nb = blocks // k + (1 if j < blocks % k else 0)
+        stop = min(u.rows, start + nb * align)
+        out.append(Unit(u.name, stop - start, u.cols, u.row0 + start, u.full_rows or u.rows))
+        start = stop
+    return out
+
+
+def plan_units(shapes: Sequence[Tuple[str, int, int]], world: int, nsamples: int, seqlen: int, blocksize: int = 128,
+               row_slabs: int = 1) -> Tuple[List[Unit], List[float], List[List[int]]]:
+    """Units (Linears or row slabs), their costs and the per-rank assignment for the Linears `shapes` = (name, R, C)
+    hooked in one forward pass.  row_slabs: 0 = whole Linears only; 1 = split the costliest Linear into as many slabs
+    as ranks would otherwise idle (fewer Linears than ranks: LLaMA's true-sequential [o] and [down] groups);
+    k >= 2 = split every Linear into k slabs.  A slab owner accumulates the full Hessian and runs the full
+    factorization chain (they depend on H only), so slabs shard only the row-proportional work: the trailing
+    updates R*C^2 and the column loop."""
+    units = [Unit(n, r, c) for (n, r, c) in shapes]
+    cost = lambda u: unit_cost(u, nsamples, seqlen, blocksize)
+    if row_slabs >= 2:
+        units = [s for u in units for s in split_rows(u, row_slabs)]
+    elif row_slabs == 1 and world > len(units):
+        big = max(range(len(units)), key=lambda i: (cost(units[i]), -i))
+        units = units[:big] + split_rows(units[big], world - len(units) + 1) + units[big + 1:]
+    costs = [cost(u) for u in units]
+    return units, costs, assign_units(costs, world)
 
 
 def hessian_cost(u: Unit, nsamples: int, seqlen: int) -> float:

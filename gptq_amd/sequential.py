@@ -45,10 +45,19 @@ class QuantArgs:
     nearest: bool = False
     blocksize: int = 128
     hessian_defer: int = 8      # hook inputs folded into H per launch (gptq_amd.gptq.HESSIAN_DEFER)
+    row_slabs: int = 1          # multi-GPU only, gptq_amd.parallel.plan_units: 0 never, 1 when ranks would idle, k >= 2 always
 
 
 class _Stop(Exception):
     pass
+
+
+class _RowSlab(nn.Module):
+    """Rows [r0, r1) of a Linear's weight as a layer of its own (a view: same storage), for a row-slab GPTQ solve."""
+
+    def __init__(self, linear, r0, r1):
+        super().__init__()
+        self.weight = nn.Parameter(linear.weight.data[r0:r1], requires_grad=False)
 
 
 def _family(model):
@@ -155,55 +164,74 @@ def quantize_sequential(model, dataloader, dev, args: QuantArgs, group=None) -> 
         else:
             groups = [list(full.keys())]
         for names in groups:
-            subset = {n: full[n] for n in names}
             units, assignment = None, None
             if world > 1:
-                units = [par.Unit(n, subset[n].out_features, subset[n].in_features) for n in names]
-                costs = [par.unit_cost(u, args.nsamples, model.seqlen, args.blocksize) for u in units]
-                assignment = par.assign_units(costs, world)
-                subset = {names[k]: full[names[k]] for k in assignment[rank]}
-            solvers = {}
-            for name, lin in subset.items():
-                solvers[name] = GPTQ(lin)
-                solvers[name].quantizer = Quantizer()
-                solvers[name].quantizer.configure(args.wbits, perchannel=True, sym=args.sym, mse=False)
+                units, _, assignment = par.plan_units([(n, full[n].out_features, full[n].in_features) for n in names], world,
+                                                      args.nsamples, model.seqlen, args.blocksize, args.row_slabs)
+                mine = list(assignment[rank])
+            else:
+                units = [par.Unit(n, full[n].out_features, full[n].in_features) for n in names]
+                mine = list(range(len(units)))
+            solvers = {}                                        # unit index -> GPTQ
+            for k in mine:
+                u = units[k]
+                target = full[u.name] if not u.full_rows else _RowSlab(full[u.name], u.row0, u.row0 + u.rows)
+                solvers[k] = GPTQ(target)
+                solvers[k].quantizer = Quantizer()
+                solvers[k].quantizer.configure(args.wbits, perchannel=True, sym=args.sym, mse=False)
+            by_module = {}
+            for k in mine:
+                by_module.setdefault(units[k].name, []).append(solvers[k])
 
             def hook(name):
                 def fn(_, inp, out):
-                    solvers[name].add_batch(inp[0].data, out.data)
+                    for sv in by_module[name]:                  # slabs of one Linear share its input (and its Hessian)
+                        sv.add_batch(inp[0].data, out.data)
                 return fn
 
-            handles = [lin.register_forward_hook(hook(name)) for name, lin in subset.items()]
+            handles = [full[name].register_forward_hook(hook(name)) for name in by_module]
             for j in range(args.nsamples):
                 outs[j] = _run_layer(layer, inps[j], kwargs)
             for h in handles:
                 h.remove()
             fasterquant_many(list(solvers.values()), blocksize=args.blocksize, percdamp=args.percdamp,
                              groupsize=args.groupsize, actorder=args.act_order, static_groups=args.static_groups)
-            for name in subset:
-                key = f"{fam['prefix']}.{i}.{name}"
-                quantizers[key] = solvers[name].quantizer
-                records.append(dict(name=key, error=solvers[name].error))
+            for k in mine:
+                u = units[k]
+                key = f"{fam['prefix']}.{i}.{u.name}"
+                if not u.full_rows:
+                    quantizers[key] = solvers[k].quantizer
+                records.append(dict(name=key if not u.full_rows else f"{key}[{u.row0}:{u.row0 + u.rows}]",
+                                    error=solvers[k].error))
                 if world == 1:
-                    solvers[name].free()
+                    solvers[k].free()
             if world > 1:
                 local = {}
-                for k in assignment[rank]:
-                    sv = solvers[names[k]]
+                for k in mine:
+                    sv = solvers[k]
                     st, zt = _packed_tables(sv, args.groupsize)
                     local[k] = (pack_codes(sv.codes, args.wbits), st.contiguous(), zt.contiguous())
                     sv.free()
                 everything = par.allgather_packed(local, units, assignment, args.wbits, args.groupsize, group=group)
-                for k, name in enumerate(names):
+                grids = {}                                      # name -> [(row0, scale col, zero col)] of gathered slabs
+                for k, u in enumerate(units):
                     qw, st, zt = everything[k]
-                    lin = full[name]
-                    lin.weight.data = dequant_packed(qw.to(dev), st.t().contiguous().to(dev), zt.t().contiguous().to(dev),
-                                                     args.wbits, args.groupsize, dtype=lin.weight.dtype)
+                    lin = full[u.name]
+                    W = dequant_packed(qw.to(dev), st.t().contiguous().to(dev), zt.t().contiguous().to(dev),
+                                       args.wbits, args.groupsize, dtype=lin.weight.dtype)
+                    if u.full_rows:
+                        lin.weight.data[u.row0:u.row0 + u.rows] = W
+                    else:
+                        lin.weight.data = W
+                    grids.setdefault(u.name, []).append((u.row0, st[:, -1:].clone(), zt[:, -1:].clone()))
+                for name, parts in grids.items():
                     key = f"{fam['prefix']}.{i}.{name}"
-                    if key not in quantizers:                   # grids of Linears other ranks solved
+                    if key not in quantizers:                   # grids of Linears (or slabs) other ranks solved
+                        parts.sort(key=lambda t: t[0])
                         q = Quantizer()
                         q.configure(args.wbits, perchannel=True, sym=args.sym, mse=False)
-                        q.scale, q.zero = st[:, -1:].clone(), zt[:, -1:].clone()
+                        q.scale = torch.cat([p[1] for p in parts], 0)
+                        q.zero = torch.cat([p[2] for p in parts], 0)
                         quantizers[key] = q
         for j in range(args.nsamples):                        # opt.py:216-217: next block sees quantized outputs
             outs[j] = _run_layer(layer, inps[j], kwargs)

@@ -172,7 +172,7 @@ def test_pack_save_load_generate_roundtrip(hip_device, tmp_path):
     assert abs(ppl_packed - ppl_dense) <= 2e-2 * ppl_dense
 
 
-def _sharded_worker(rank, world, port, out_path):
+def _sharded_worker(rank, world, port, out_path, row_slabs=1):
     import os
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -183,7 +183,8 @@ def _sharded_worker(rank, world, port, out_path):
         gmod.VERBOSE = False
         dev = torch.device("cuda:0")
         model, calib = _sharding_case()
-        opt_sequential(model, calib, dev, QuantArgs(wbits=4, nsamples=8, groupsize=32, static_groups=True))
+        opt_sequential(model, calib, dev, QuantArgs(wbits=4, nsamples=8, groupsize=32, static_groups=True,
+                                                    row_slabs=row_slabs))
         if rank == 0:
             torch.save({k: v.cpu() for k, v in model.state_dict().items()}, out_path)
     finally:
@@ -204,10 +205,12 @@ def _sharding_case():
 
 
 @pytest.mark.timeout(300)
-def test_module_sharded_two_ranks_match_single_process(hip_device, tmp_path):
+@pytest.mark.parametrize("row_slabs", [1, 2])
+def test_module_sharded_two_ranks_match_single_process(hip_device, tmp_path, row_slabs):
     """SURVEY 8e at driver level: 2 ranks (sharing the one GPU of the test box, gloo rendezvous) deal the
-    Linears of every block between them, all-gather the packed weights and rebuild the block; the result
-    must equal the single-process quantization bit for bit."""
+    Linears of every block between them -- whole (row_slabs=1) or as row slabs (row_slabs=2: every Linear cut in
+    two, each half solved by one rank with the full Hessian) -- all-gather the packed weights and rebuild the
+    block; the result must equal the single-process quantization bit for bit."""
     import socket
     import torch.multiprocessing as mp
     import gptq_amd.gptq as gmod
@@ -220,7 +223,7 @@ def test_module_sharded_two_ranks_match_single_process(hip_device, tmp_path):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / "sharded.pt")
-    mp.spawn(_sharded_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_sharded_worker, args=(2, port, out, row_slabs), nprocs=2, join=True)
     got = torch.load(out, weights_only=True)
     assert got.keys() == ref.keys()
     for k in ref:

@@ -93,3 +93,20 @@ def test_assign_units_keeps_bundles_together():
         assert max(loads) <= 1.01 * min(loads)
     # without bundles: plain LPT, deterministic
     assert par.assign_units([5.0, 3.0, 3.0, 2.0, 2.0], 2) == [[0, 3], [1, 2, 4]]
+
+
+def test_plan_units_row_slabs():
+    """Row slabs (second axis): fewer Linears than ranks -> the costliest one is cut so nobody idles."""
+    from gptq_amd import parallel as par
+    units, costs, a = par.plan_units([("down_proj", 8192, 22016)], 8, 128, 2048)
+    assert [(u.row0, u.rows, u.full_rows) for u in units] == [(1024 * j, 1024, 8192) for j in range(8)]
+    assert sorted(i for r in a for i in r) == list(range(8)) and all(len(r) == 1 for r in a)
+    units, _, a = par.plan_units([("o_proj", 4096, 4096)], 3, 128, 2048)
+    assert [u.rows for u in units] == [1408, 1408, 1280] and sum(u.rows for u in units) == 4096
+    assert all(u.row0 % 128 == 0 for u in units)
+    units, _, a = par.plan_units([("q", 256, 128), ("fc1", 512, 128)], 2, 8, 128, row_slabs=0)
+    assert all(u.full_rows == 0 for u in units)
+    units, _, a = par.plan_units([("q", 128, 128), ("fc1", 512, 128)], 2, 8, 128, row_slabs=2)
+    assert [(u.name, u.row0, u.rows) for u in units] == [("q", 0, 128), ("fc1", 0, 256), ("fc1", 256, 256)]
+    qshape, gshape = par.packed_shapes(units[1], 4, 32)
+    assert qshape == (128 // 32 * 4, 256) and gshape == (256, 4)
