@@ -631,37 +631,57 @@ __global__ __launch_bounds__(512) void hessian16_big_kernel(ProbGroup pg, BigPla
   }
 }
 
-// Four workgroups per K-split tile: sum its partial tiles in run order, then the usual epilogue.
-__global__ __launch_bounds__(512) void hessian16_big_fixup(ProbGroup pg, BigPlan plan, int nk_all) {
+// 32 single-wave workgroups per K-split tile (block pair row t = blockIdx.y, wave slice = blockIdx.z): sum the
+// partial tiles in run order -- loads of four partials in flight, the adds stay in order -- then the usual epilogue.
+__global__ __launch_bounds__(64) void hessian16_big_fixup(ProbGroup pg, BigPlan plan, int nk_all) {
   const int l = blockIdx.x;
   const int tile = plan.dp_tiles + l;
   const int prob = prob_of_tile(pg, tile);
   const int ldh = pg.ldh[prob];
   int ti, tj;
   hessian_tile_of(tile - pg.tile_start[prob], pg.C[prob] / BT, ti, tj);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = blockIdx.z;
   const int wm = wave >> 2, wn = wave & 3;
   const int first = l * nk_all, last = first + nk_all - 1;
   const int w0 = first / plan.chunk, w1 = min(last / plan.chunk, plan.workers - 1);
   float* __restrict__ H = pg.H[prob];
   const float alpha = pg.alpha[prob], beta = pg.beta[prob];
-  {
-    const int t = blockIdx.y;                                 // one 32-row block pair per workgroup
-    float v[2][16];
+  const int t = blockIdx.y;
+  float v[2][16];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+  for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) v[u][e] = 0.f;
-    for (int w = w0; w <= w1; ++w) {
-      const int seg = (w * plan.chunk < first) ? 1 : 0;       // the run began in the previous tile
-      const float* __restrict__ part = plan.ws + ((long)w * 2 + seg) * BTILE_FLOATS;
+    for (int e = 0; e < 16; ++e) v[u][e] = 0.f;
+  auto part_of = [&](int w) {
+    const int seg = (w * plan.chunk < first) ? 1 : 0;         // the run began in the previous tile
+    return plan.ws + ((long)w * 2 + seg) * BTILE_FLOATS;
+  };
+  int w = w0;
+  for (; w + 3 <= w1; w += 4) {
+    float x[4][2][16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float* __restrict__ part = part_of(w + j);
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) v[u][e] += part[big_part_index(wave, t, u, e, lane)];
+        for (int e = 0; e < 16; ++e) x[j][u][e] = part[big_part_index(wave, t, u, e, lane)];
     }
-    big_epilogue_rows(H, ldh, ti, tj, wm, wn, lane, t, v, alpha, beta);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[u][e] += x[j][u][e];
   }
+  for (; w <= w1; ++w) {
+    const float* __restrict__ part = part_of(w);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[u][e] += part[big_part_index(wave, t, u, e, lane)];
+  }
+  big_epilogue_rows(H, ldh, ti, tj, wm, wn, lane, t, v, alpha, beta);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1040,7 +1060,7 @@ static int hessian_launch_big(const HostProb* probs, int n_prob, int n_x, int x_
       else if (bring_env == 5) HBIG(false, 5, 0);
       else HBIG(false, BRING_DEFAULT, 0);
 #undef HBIG
-      if (plan.left_tiles > 0) hessian16_big_fixup<<<dim3(plan.left_tiles, 4), 512, 0, s>>>(pg, plan, nk_all);
+      if (plan.left_tiles > 0) hessian16_big_fixup<<<dim3(plan.left_tiles, 4, 8), 64, 0, s>>>(pg, plan, nk_all);
     }
   }
   GPTQ_CHECK_LAUNCH("hessian16_big_kernel");
