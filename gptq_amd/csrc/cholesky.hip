@@ -433,8 +433,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void trtri_step1_kernel(const float* 
   Operand<float> a{L + rm * Cp + ka, Cp, 1, NB, true};            // B[m][k]
   Operand<float> b{Linv + ka * Cp + cn, 1, Cp, NB, true};         // Ainv[k][n], lower: k >= n
   float* Tt = Linv + cn * Cp + rm;                                // T^T lives at [n][m]
-  gemm_tile<float, float, true, false>(a, b, tj * NB, s * NB, smem,
-                                       Epilogue{Tt, 1, Cp, EPI_STORE, TRI_ALL, 0.f, 0.f});   // transposed store
+  // T^T[n][m] = sum_k Ainv[k][n] * B[m][k]: the operands swap roles so that the tile comes out already transposed
+  // and its rows (m contiguous) are stored coalesced; products commute, so the bits are those of B * Ainv
+  gemm_tile<float, float, false, true>(b, a, tj * NB, s * NB, smem,
+                                       Epilogue{Tt, Cp, 1, EPI_STORE, TRI_ALL, 0.f, 0.f});
 }
 
 __global__ __launch_bounds__(GEMM_THREADS) void trtri_step2_kernel(float* __restrict__ Linv, int Cp,
