@@ -34,6 +34,8 @@ _SIGNATURES = {
     "gptq_fasterquant_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i]),
     "gptq_fasterquant": (C.c_int, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _p, _p, _i, _p, _p, _p, _p,
                                    _p, _p, _p, _z, _p]),
+    "gptq_fasterquant_rows": (C.c_int, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _p, _p, _i, _p, _p, _p, _p,
+                                        _p, _p, _p, _p, _z, _p]),
     "gptq_pack_weights": (C.c_int, [_p, _i, _i, _i, _i, _p, _p, _i, _p, _p]),
     "gptq_pack_codes": (C.c_int, [_p, _i, _i, _i, _i, _p, _p]),
     "gptq_dequant_packed": (C.c_int, [_p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _p]),

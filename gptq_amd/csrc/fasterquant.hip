@@ -465,12 +465,12 @@ extern "C" size_t gptq_fasterquant_workspace_bytes(int R, int C, int blocksize, 
   return carve_solve(nullptr, R, C, blocksize, groupsize, actorder).total;
 }
 
-extern "C" int gptq_fasterquant(float* W, int ldw, float* H, int ldh, int R, int C, int bits, int sym,
-                                int blocksize, float percdamp, int groupsize, int actorder,
-                                int static_groups, float* scale_io, float* zero_io, int preset,
-                                float* group_scale, float* group_zero, int32_t* perm_out,
-                                uint8_t* codes, float* error_out, int32_t* info, void* workspace,
-                                size_t workspace_bytes, gptq_stream_t stream) {
+extern "C" int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R, int C, int bits, int sym,
+                                     int blocksize, float percdamp, int groupsize, int actorder,
+                                     int static_groups, float* scale_io, float* zero_io, int preset,
+                                     float* group_scale, float* group_zero, int32_t* perm_out,
+                                     uint8_t* codes, float* error_out, float* row_loss, int32_t* info,
+                                     void* workspace, size_t workspace_bytes, gptq_stream_t stream) {
   GPTQ_CHECK_ARG(W && H && scale_io && zero_io && error_out && workspace, "gptq_fasterquant: null pointer");
   GPTQ_CHECK_ARG(R > 0 && C > 0 && ldw >= C && ldh >= C, "gptq_fasterquant: bad sizes");
   GPTQ_CHECK_ARG(R <= 65535, "gptq_fasterquant: R too large");
@@ -596,6 +596,18 @@ extern "C" int gptq_fasterquant(float* W, int ldw, float* H, int ldh, int R, int
     GPTQ_CHECK_HIP(hipMemcpyAsync(group_zero, ws.ztab, sizeof(float) * (size_t)R * G, hipMemcpyDeviceToDevice, s));
   }
   sum_kernel<<<1, 256, 0, s>>>(ws.loss, R, error_out);
+  if (row_loss) GPTQ_CHECK_HIP(hipMemcpyAsync(row_loss, ws.loss, sizeof(float) * (size_t)R, hipMemcpyDeviceToDevice, s));
   GPTQ_CHECK_LAUNCH("gptq_fasterquant");
   return GPTQ_OK;
+}
+
+extern "C" int gptq_fasterquant(float* W, int ldw, float* H, int ldh, int R, int C, int bits, int sym,
+                                int blocksize, float percdamp, int groupsize, int actorder,
+                                int static_groups, float* scale_io, float* zero_io, int preset,
+                                float* group_scale, float* group_zero, int32_t* perm_out,
+                                uint8_t* codes, float* error_out, int32_t* info, void* workspace,
+                                size_t workspace_bytes, gptq_stream_t stream) {
+  return gptq_fasterquant_rows(W, ldw, H, ldh, R, C, bits, sym, blocksize, percdamp, groupsize, actorder, static_groups,
+                               scale_io, zero_io, preset, group_scale, group_zero, perm_out, codes, error_out, nullptr,
+                               info, workspace, workspace_bytes, stream);
 }

@@ -55,6 +55,10 @@ SHARE_INPUT_HESSIANS = True
 # (1.31 ms for fc2 + the three C = 2048 Hessians together vs 1.06 + 0.27 ms apart: the larger K-split last round
 # eats what the shared launch saves), so launches stay per width by default.
 MIX_WIDTHS = False
+# fasterquant_many solves objects that share a Hessian as one problem over the concatenation of their rows: one
+# factorization chain and one column loop for q/k/v (rows of W are independent given H, gptq.py:262-276), bit for
+# bit the per-object results.
+JOINT_SOLVE = True
 
 
 def _input_signature(o):
@@ -149,9 +153,28 @@ def fasterquant_many(solvers, blocksize=128, percdamp=.01, groupsize=-1, actorde
     if not solvers:
         return
     flush_pending()
-    for g in solvers:                    # shared running Hessians: private copies, on the caller's stream,
-        g._materialize()                 # before the solves fan out over the lanes
+    # Objects that share one running Hessian (SHARE_INPUT_HESSIANS) and are all solved here become ONE problem over
+    # the concatenation of their rows (_JointSolve); the others take private copies of H on the caller's stream,
+    # before the solves fan out over the lanes.
+    chosen = {id(g) for g in solvers}
+    units, grouped = [], set()
+    if JOINT_SOLVE:
+        for g in solvers:
+            if g._leader is None and g._followers and id(g) not in grouped:
+                members = [g] + [f for f in g._followers if id(f) in chosen]
+                if len(members) > 1 and _JointSolve.compatible(members):
+                    units.append(_JointSolve(members))
+                    grouped.update(id(m) for m in members)
+    for g in solvers:
+        if id(g) in grouped:
+            continue
+        g._materialize()
         g._release_followers()
+        units.append(g)
+    for u in units:
+        if isinstance(u, _JointSolve):
+            u.detach()                   # followers outside this call copy H now; the group keeps the leader's
+    solvers = units
     by_dev = {}
     for g in solvers:
         by_dev.setdefault(g.dev, []).append(g)
@@ -199,6 +222,110 @@ def fasterquant_many(solvers, blocksize=128, percdamp=.01, groupsize=-1, actorde
             states += mine
     for g, state in states:
         g._solve_finish(state)
+
+
+class _JointSolve:
+    """GPTQ objects sharing one running Hessian, solved as one Linear whose rows are theirs stacked (leader first)."""
+
+    def __init__(self, members):
+        self.members = members
+        self.dev = members[0].dev
+        self.columns = members[0].columns
+        self.rows = sum(m.rows for m in members)
+
+    @staticmethod
+    def compatible(members):
+        q0 = members[0].quantizer
+        for m in members:
+            q = m.quantizer
+            if not isinstance(m.layer, nn.Linear) and type(m.layer).__name__ != "_RowSlab":
+                return False
+            if int(q.maxq) != int(q0.maxq) or bool(q.sym) != bool(q0.sym) or int(q.maxq) < 0:
+                return False
+            if q.scale.numel() == m.rows and bool(q.ready()):          # a preset grid (gptq.py:181): solve alone
+                return False
+            if m.columns != members[0].columns or m.dev != members[0].dev or m._H is None:
+                return False
+        return True
+
+    @property
+    def _H(self):
+        return self.members[0]._H
+
+    def detach(self):
+        L = self.members[0]
+        inside = {id(m) for m in self.members}
+        for f in list(L._followers):
+            if id(f) not in inside:
+                f._materialize()
+        for m in self.members[1:]:
+            L._followers.remove(m)
+            m._leader = None
+
+    def _solve_enqueue(self, blocksize, percdamp, groupsize, actorder, static_groups):
+        L = self.members[0]
+        q = L.quantizer
+        bits = int(getattr(q, "wbits", 0)) or (int(q.maxq) + 1).bit_length() - 1
+        tick = time.time()
+        W = torch.cat([m.layer.weight.data.float() for m in self.members], 0).contiguous()
+        R, C = W.shape
+        dev = self.dev
+        H = L._H
+        for m in self.members:
+            m._applied = m.nsamples if m.nsamples else m._applied
+            m._H = None                  # consumed (gptq.py:141-142)
+        G = -(-C // groupsize) if groupsize > 0 else 0
+        scale = torch.zeros(R, device=dev, dtype=torch.float32)
+        zero = torch.zeros(R, device=dev, dtype=torch.float32)
+        gscale = torch.empty((R, G), device=dev, dtype=torch.float32) if G else None
+        gzero = torch.empty((R, G), device=dev, dtype=torch.float32) if G else None
+        perm = torch.empty(C, device=dev, dtype=torch.int32) if actorder else None
+        codes = torch.empty((R, C), device=dev, dtype=torch.uint8)
+        stat = torch.zeros(2, device=dev, dtype=torch.float32)
+        row_loss = torch.empty(R, device=dev, dtype=torch.float32)
+        info = stat[1:].view(torch.int32)
+        lib = _lib.load()
+        nbytes = lib.gptq_fasterquant_workspace_bytes(R, C, int(blocksize), int(groupsize), int(bool(actorder)),
+                                                      int(bool(static_groups)))
+        ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        with torch.cuda.device(dev):
+            _lib.call("gptq_fasterquant_rows", _lib.ptr(W), W.stride(0), _lib.ptr(H), H.stride(0), R, C, bits,
+                      int(bool(q.sym)), int(blocksize), float(percdamp), int(groupsize), int(bool(actorder)),
+                      int(bool(static_groups)), _lib.ptr(scale), _lib.ptr(zero), 0, _lib.ptr(gscale),
+                      _lib.ptr(gzero), _lib.ptr(perm), _lib.ptr(codes), _lib.ptr(stat), _lib.ptr(row_loss),
+                      _lib.ptr(info), _lib.ptr(ws), nbytes, _lib.stream(dev))
+            bounds, r0 = [], 0
+            for m in self.members:
+                bounds.append((r0, r0 + m.rows))
+                r0 += m.rows
+            errors = torch.stack([row_loss[a:b].sum() for a, b in bounds])
+        return dict(tick=tick, W=W, H=H, scale=scale, zero=zero, gscale=gscale, gzero=gzero, perm=perm, codes=codes,
+                    stat=stat, ws=ws, row_loss=row_loss, errors=errors, bounds=bounds,
+                    static_groups=bool(static_groups))
+
+    def _solve_finish(self, st):
+        host = st["stat"].cpu()
+        bad = int(host[1:].view(torch.int32).item())
+        if bad:
+            raise torch.linalg.LinAlgError(
+                f"fasterquant: the damped Hessian is not positive-definite (pivot {bad}); cf. torch.linalg.cholesky")
+        errors = st["errors"].cpu()
+        for m, (a, b), err in zip(self.members, st["bounds"], errors):
+            q = m.quantizer
+            m.error = float(err.item())
+            if VERBOSE:
+                print('time %.2f' % (time.time() - st["tick"]))
+                print('error', m.error)
+            q.maxq = q.maxq.to(self.dev)
+            q.scale = st["scale"][a:b].reshape(-1, 1)
+            q.zero = st["zero"][a:b].reshape(-1, 1)
+            m.Hinv = st["H"]
+            m.codes = st["codes"][a:b]
+            m.group_scale = st["gscale"][a:b] if st["gscale"] is not None else None
+            m.group_zero = st["gzero"][a:b] if st["gzero"] is not None else None
+            m.perm = st["perm"]
+            m.static_groups = st["static_groups"]
+            m.layer.weight.data = st["W"][a:b].reshape(m.layer.weight.shape).to(m.layer.weight.data.dtype)
 
 
 class GPTQ:

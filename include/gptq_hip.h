@@ -142,6 +142,18 @@ int gptq_fasterquant(float* W, int ldw, float* H, int ldh, int R, int C, int bit
                      float* group_zero, int32_t* perm_out, uint8_t* codes, float* error_out,
                      int32_t* info, void* workspace, size_t workspace_bytes, gptq_stream_t stream);
 
+/* The same solve with the per-row losses as an extra output: row_loss (nullable, device fp32 [R]) receives
+ * sum_j Losses[r, j] of every row (error_out = their sum).  Rows are independent problems given H (per-row grids,
+ * per-row error feedback, gptq.py:262-276), so the R rows may be the CONCATENATION of several Linears that were fed
+ * the same inputs (q/k/v, gate/up: same H): one factorization chain serves all of them, the column loop runs over
+ * all their rows at once, and row_loss lets the caller report each Linear's own `error`. */
+int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R, int C, int bits, int sym,
+                          int blocksize, float percdamp, int groupsize, int actorder, int static_groups,
+                          float* scale_io, float* zero_io, int preset, float* group_scale,
+                          float* group_zero, int32_t* perm_out, uint8_t* codes, float* error_out,
+                          float* row_loss, int32_t* info, void* workspace, size_t workspace_bytes,
+                          gptq_stream_t stream);
+
 /* ---------------------------------------------------------------------------
  * Bit packing -- replaces Quant3Linear.pack (quant.py:152-187) and the int4
  * layout of Quant4Linear.__init__ (zeroShot/models/quant.py:176-185).

@@ -430,6 +430,50 @@ def test_shared_input_hessians_match_private_ones(G, defer):
         gm.HESSIAN_DEFER, gm.SHARE_INPUT_HESSIANS = old
 
 
+@pytest.mark.parametrize("kw", [dict(groupsize=-1), dict(groupsize=128, static_groups=True),
+                                dict(groupsize=128, actorder=True), dict(groupsize=64)])
+def test_joint_solve_of_shared_hessian_objects_matches_separate_solves(G, kw):
+    """q/k/v-style objects that share one Hessian are solved by fasterquant_many as ONE problem over their stacked rows
+    (one factorization chain, one column loop): codes, weights, grids and act-order permutation must be bit for bit
+    those of separate solves; each object's `error` is the sum of its own rows' losses."""
+    gm = G.gptq
+    gm.VERBOSE = False
+    old = (gm.HESSIAN_DEFER, gm.JOINT_SOLVE)
+    gm.HESSIAN_DEFER = 2
+    try:
+        res = {}
+        for joint in (False, True):
+            gm.JOINT_SOLVE = joint
+            g2 = torch.Generator().manual_seed(21)
+            objs = []
+            for R in (96, 256, 64):                              # different heights, same input
+                gp = G.GPTQ(make_linear((torch.randn(R, 512, generator=g2) * 0.02).half().cuda()))
+                gp.quantizer = G.Quantizer(); gp.quantizer.configure(4, perchannel=True, sym=False, mse=False)
+                objs.append(gp)
+            lone = G.GPTQ(make_linear((torch.randn(128, 512, generator=g2) * 0.02).half().cuda()))
+            lone.quantizer = G.Quantizer(); lone.quantizer.configure(4, perchannel=True, sym=False, mse=False)
+            for _ in range(4):
+                x = (torch.randn(1, 300, 512, generator=g2) * (1 + torch.arange(512) % 5)).half().cuda()
+                y = (torch.randn(1, 300, 512, generator=g2) * (1 + torch.arange(512) % 3)).half().cuda()
+                for gp in objs:
+                    gp.add_batch(x, None)
+                lone.add_batch(y, None)
+            G.fasterquant_many(objs + [lone], blocksize=128, percdamp=0.01, **kw)
+            res[joint] = [(o.codes.clone(), o.layer.weight.data.clone(), o.quantizer.scale.clone(),
+                           o.quantizer.zero.clone(), o.error, None if o.perm is None else o.perm.clone(),
+                           None if o.group_scale is None else o.group_scale.clone()) for o in objs + [lone]]
+        for a, b in zip(res[False], res[True]):
+            for i in (0, 1, 2, 3):
+                assert torch.equal(a[i], b[i])
+            assert abs(a[4] - b[4]) <= 1e-5 * abs(a[4])
+            if a[5] is not None:
+                assert torch.equal(a[5], b[5])
+            if a[6] is not None:
+                assert torch.equal(a[6], b[6])
+    finally:
+        gm.HESSIAN_DEFER, gm.JOINT_SOLVE = old
+
+
 def test_shared_input_hessians_leader_freed_or_solved_first(G):
     gm = G.gptq
     gm.VERBOSE = False
