@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--hessian-defer", type=int, default=8,
                     help="hook inputs folded into H per launch (gptq_amd.gptq.HESSIAN_DEFER; 1 = per call like the reference)")
     ap.add_argument("--serial-solve", action="store_true", help="solve the Linears one by one instead of on concurrent streams")
+    ap.add_argument("--no-lazy-hessians", action="store_true",
+                    help="fold every Linear's inputs into its Hessian as the hooks fire (gptq_amd.gptq.LAZY_HESSIANS = False)")
     ap.add_argument("--no-shared-inputs", action="store_true",
                     help="give q/k/v private calibration tensors (their Hessians are then accumulated three times)")
     ap.add_argument("--solve-streams", type=int, default=0, help="concurrent solves (0 = library default)")
@@ -89,6 +91,7 @@ def main():
     _lib.load()
     gmod.VERBOSE = False
     gmod.HESSIAN_DEFER = args.hessian_defer
+    gmod.LAZY_HESSIANS = not args.no_lazy_hessians
 
     # ---- unit list: `world` blocks' worth of Linears, dealt by cost -----------------------------
     units = [par.Unit(f"b{b}.{n}", r, c) for b in range(world) for (n, r, c) in SHAPES]
@@ -150,7 +153,8 @@ def main():
         for j in range(args.nsamples):
             for i in mine:
                 solvers[i].add_batch(acts[i][j:j + 1], None)
-        gmod.flush_pending()
+        if not gmod.LAZY_HESSIANS:                 # lazy: the narrow Linears' updates are folded beside fc2's solve
+            gmod.flush_pending()
         e1.record()
         gmod.FLUSH_EVENTS = None
         # 2. solve + pack for every Linear of the block (opt.py:189-214); the solves are independent and go out

@@ -25,6 +25,7 @@ _SIGNATURES = {
     "gptq_hessian_accum_multi": (C.c_int, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "gptq_hessian_accum_group": (C.c_int, [_i, _p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p]),
     "gptq_hessian_accum_mixed": (C.c_int, [_i, _p, _p, _p, _i, _i, _p, _p, _i, _p, _i, _p]),
+    "gptq_hessian_cu_limit": (C.c_int, [_i]),
     "gptq_symmetrize": (C.c_int, [_p, _i, _i, _p]),
     "gptq_find_params": (C.c_int, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _i, _p]),
     "gptq_quantize_rows": (C.c_int, [_p, _i, _i, _i, _p, _p, _i, _p]),

@@ -975,6 +975,8 @@ using namespace gptq;
 // One H update per problem; every problem brings `n_x` equally shaped slabs [tokens, C] (row-major, ldx).
 struct HostProb { float* H; const void* const* xs; float alpha, beta; int C, ldx, ldh; };
 
+static thread_local int g_cu_limit = 0;   // gptq_hessian_cu_limit
+
 // GPTQ_HESS_BIG: 0 = 128 x 128 kernel only, 1 = default, 2 = 256 x 256 kernel whenever the shapes allow,
 //                3 = like 2 but without the K-split last round
 static int hess_big_env() {
@@ -996,6 +998,7 @@ static int hessian_launch_big(const HostProb* probs, int n_prob, int n_x, int x_
   int dev = 0, n_cu = 256;
   GPTQ_CHECK_HIP(hipGetDevice(&dev));
   GPTQ_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  if (g_cu_limit > 0) n_cu = std::max(8, std::min(n_cu, g_cu_limit));   // leave the other CUs to concurrent streams
   for (int p0 = 0; p0 < n_prob; p0 += MAX_PROB) {
     const int np = std::min(MAX_PROB, n_prob - p0);
     for (int i0 = 0; i0 < n_x; i0 += MAX_XLIST) {
@@ -1229,6 +1232,12 @@ extern "C" int gptq_hessian_accum(float* H, int ldh, const void* X, int x_dtype,
   GPTQ_CHECK_ARG(X != nullptr, "gptq_hessian_accum: null pointer");
   const void* xs[1] = {X};
   return gptq_hessian_accum_multi(H, ldh, xs, 1, x_dtype, ldx, C, tokens, nsamples_before, batch, stream);
+}
+
+extern "C" int gptq_hessian_cu_limit(int n_cu) {
+  GPTQ_CHECK_ARG(n_cu >= 0, "gptq_hessian_cu_limit: negative");
+  g_cu_limit = n_cu;
+  return GPTQ_OK;
 }
 
 extern "C" int gptq_symmetrize(float* A, int lda, int n, gptq_stream_t stream) {

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import math
 import time
+import weakref
 
 import torch
 import torch.nn as nn
@@ -40,7 +41,8 @@ HESSIAN_DEFER = 1
 # the cache is kept by default; set True for the reference's behaviour when memory is tight.
 EMPTY_CACHE_ON_FREE = False
 
-_DIRTY = {}     # id -> GPTQ objects holding deferred hook inputs
+_DIRTY = weakref.WeakValueDictionary()   # id -> GPTQ objects holding deferred hook inputs (dropped objects vanish)
+_LIVE = weakref.WeakSet()                # GPTQ objects whose Hessian is still being accumulated
 FLUSH_EVENTS = None   # set to a list to collect ([C per problem], n_slabs, start_event, end_event) per Hessian call
 
 
@@ -59,22 +61,28 @@ MIX_WIDTHS = False
 # factorization chain and one column loop for q/k/v (rows of W are independent given H, gptq.py:262-276), bit for
 # bit the per-object results.
 JOINT_SOLVE = True
+# When add_batch reaches HESSIAN_DEFER, fold only the widest Linears' inputs (their Hessians are the bulk of the flops
+# and sit on the critical path of the block); the narrower ones keep collecting inputs -- references, no copies, up to
+# LAZY_MAX_BYTES -- and fasterquant_many folds them on the side lanes, beside the widest Linear's solve, which is
+# latency-bound and leaves the chip idle.  Their launches are sized for LAZY_CUS compute units per lane so that the
+# solve's small kernels always find free ones.
+LAZY_HESSIANS = True
+LAZY_MAX_BYTES = 16 << 30
+LAZY_CUS = 96
 
 
 def _input_signature(o):
-    return tuple((x.data_ptr(), tuple(x.shape), tuple(x.stride()), x.dtype, b) for x, b in o._pending)
+    """Identity of the deferred inputs of `o` (device buffers, shapes, strides, dtypes), kept incrementally by
+    add_batch so that planning a flush costs O(objects), not O(retained inputs)."""
+    return (len(o._pending), o._sig)
 
 
-def flush_pending():
-    """Fold every deferred hook input into its H.  Objects whose pending inputs have the same shape
-    (the Linears of one block that share in_features) go out as ONE grouped launch
-    (gptq_hessian_accum_group): alone, each brings too few 128x128 tiles to fill the 256 CUs."""
-    import ctypes
-    global _DIRTY
-    objs = [o for o in _DIRTY.values() if o._pending and o._H is not None]
-    _DIRTY = {}
+def _plan_flush():
+    """Settle who shares a running Hessian with whom for everything that holds deferred inputs; nothing is launched.
+    Returns the objects that own an H to update (leaders and singles)."""
+    objs = [o for o in list(_DIRTY.values()) if o._pending and o._H is not None]
     if not objs:
-        return
+        return []
     sigs = {id(o): _input_signature(o) for o in objs}
     # followers whose inputs stopped matching their leader's take their own copy of H first
     for o in objs:
@@ -97,10 +105,16 @@ def flush_pending():
                     L._followers.append(o)
     for o in objs:
         o._fresh = False
-    work = [o for o in objs if o._leader is None]
-    # one library call per (device, slab shape, batch structure[, width]); with MIX_WIDTHS the Linears of all widths
-    # go into the same call (gptq_hessian_accum_mixed then puts every width the 256x256-tile kernel takes into the
-    # same launches)
+    return [o for o in objs if o._leader is None]
+
+
+def _launch_flush(work):
+    """Fold the deferred inputs of `work` (objects that own their H) into their H on the CURRENT stream, and settle the
+    bookkeeping of their followers (same inputs).  One library call per (device, slab shape, batch structure[, width]);
+    with MIX_WIDTHS the Linears of all widths go into the same call (gptq_hessian_accum_mixed then puts every width
+    the 256x256-tile kernel takes into the same launches)."""
+    import ctypes
+    work = [o for o in work if o._pending and o._H is not None]
     groups = {}
     for o in work:
         x0 = o._pending[0][0]
@@ -127,10 +141,32 @@ def flush_pending():
                 if FLUSH_EVENTS is not None:
                     ev1.record()
                     FLUSH_EVENTS.append(([o.columns for o in chunk], n_x, ev0, ev1))
-    for o in objs:
-        o._applied += sum(b for _, b in o._pending)
-        o._pending = []
-        o._lower_stale = True
+    for L in work:
+        for o in [L] + list(L._followers):
+            o._applied += sum(b for _, b in o._pending)
+            o._pending = []
+            o._lower_stale = True
+            _DIRTY.pop(id(o), None)
+
+
+def flush_pending(heavy_only=False):
+    """Fold deferred hook inputs into their H on the current stream.  heavy_only (LAZY_HESSIANS): only the widest
+    Linears' (>= half the largest in_features among those waiting); the others keep collecting inputs."""
+    work = _plan_flush()
+    if heavy_only and work:
+        cmax = _widest_live()
+        work = [o for o in work if 2 * o.columns >= cmax and len(o._pending) >= max(1, int(HESSIAN_DEFER))]
+    _launch_flush(work)
+
+
+def _widest_live():
+    return max((o.columns for o in list(_LIVE) if o._H is not None), default=0)
+
+
+def _retained_bytes():
+    """Bytes of hook inputs kept alive by deferred updates (inputs shared by several objects count once per object)."""
+    return sum(len(o._pending) * o._pending[0][0].numel() * o._pending[0][0].element_size()
+               for o in list(_DIRTY.values()) if o._pending)
 
 
 _SOLVE_STREAMS = {}   # device -> pool of streams for fasterquant_many
@@ -152,7 +188,7 @@ def fasterquant_many(solvers, blocksize=128, percdamp=.01, groupsize=-1, actorde
     solvers = list(solvers)
     if not solvers:
         return
-    flush_pending()
+    _plan_flush()                        # who shares a Hessian with whom; deferred inputs are folded further down
     # Objects that share one running Hessian (SHARE_INPUT_HESSIANS) and are all solved here become ONE problem over
     # the concatenation of their rows (_JointSolve); the others take private copies of H on the caller's stream,
     # before the solves fan out over the lanes.
@@ -168,11 +204,16 @@ def fasterquant_many(solvers, blocksize=128, percdamp=.01, groupsize=-1, actorde
     for g in solvers:
         if id(g) in grouped:
             continue
+        if g._leader is not None or g._followers:      # copies of a shared H need it up to date, here and now
+            _launch_flush([g._leader or g])
         g._materialize()
         g._release_followers()
         units.append(g)
     for u in units:
         if isinstance(u, _JointSolve):
+            L = u.members[0]
+            if any(id(f) not in grouped for f in L._followers):
+                _launch_flush([L])
             u.detach()                   # followers outside this call copy H now; the group keeps the leader's
     solvers = units
     by_dev = {}
@@ -188,7 +229,10 @@ def fasterquant_many(solvers, blocksize=128, percdamp=.01, groupsize=-1, actorde
                 pool.append(torch.cuda.Stream(device=dev))
             lanes = [cur] + pool[:want - 1]          # the caller's stream carries the largest solve itself
             # seconds, roughly: ~200 us of latency-bound kernels per 128-column block + the GEMM flops at 100 TFLOP/s
-            cost = lambda g: 2e-4 * (g.columns / 128.0) + (2.0 / 3.0 * g.columns ** 3 + g.rows * g.columns ** 2) / 1e14
+            def cost(g):
+                own = g.members[0] if isinstance(g, _JointSolve) else g
+                hess = sum(x.shape[0] for x, _ in own._pending) * float(g.columns) ** 2 / 4e14   # deferred updates
+                return hess + 2e-4 * (g.columns / 128.0) + (2.0 / 3.0 * g.columns ** 3 + g.rows * g.columns ** 2) / 1e14
             order = sorted(group, key=lambda g: -cost(g))
             load = [0.0] * want                      # longest-processing-time-first onto the streams
             used, mine = lanes[1:], []
@@ -206,6 +250,17 @@ def fasterquant_many(solvers, blocksize=128, percdamp=.01, groupsize=-1, actorde
                     g._H.record_stream(st)
                 t_host = time.perf_counter()
                 with torch.cuda.stream(st):
+                    own = g.members[0] if isinstance(g, _JointSolve) else g
+                    if own._pending:                 # deferred Hessian updates: on this lane, beside the other solves
+                        beside = st is not cur and len(order) > 1
+                        if st is not cur:
+                            for x, _ in own._pending:        # inputs were allocated on the caller's stream
+                                x.record_stream(st)
+                        _lib.call("gptq_hessian_cu_limit", int(LAZY_CUS) if beside else 0)
+                        try:
+                            _launch_flush([own])
+                        finally:
+                            _lib.call("gptq_hessian_cu_limit", 0)
                     mine.append((g, g._solve_enqueue(blocksize, percdamp, groupsize, actorder, static_groups)))
                 if LANE_EVENTS is not None:
                     lane_ev[k][2] += time.perf_counter() - t_host
@@ -347,6 +402,8 @@ class GPTQ:
         self._pending = []          # deferred (x, batch) hook inputs, see HESSIAN_DEFER
         self._applied = 0           # samples already folded into _H
         self._fresh = True          # no update folded in yet and H never assigned
+        self._sig = 0               # running identity of the deferred inputs (_input_signature)
+        _LIVE.add(self)
         self._leader = None         # object whose _H this one shares (SHARE_INPUT_HESSIANS)
         self._followers = []        # objects sharing this one's _H
 
@@ -428,7 +485,13 @@ class GPTQ:
         if len(self._pending) >= max(1, int(HESSIAN_DEFER)):
             # this object is about to exceed the batch: its lock-step peers (the other Linears hooked in
             # the same forward passes) hold exactly as many inputs, so everything goes out grouped by shape
-            flush_pending()
+            if not LAZY_HESSIANS:
+                flush_pending()
+            elif 2 * self.columns >= _widest_live():          # one of the widest Linears being calibrated
+                flush_pending(heavy_only=True)
+            elif len(self._pending) % 16 == 0 and _retained_bytes() > LAZY_MAX_BYTES:
+                flush_pending()
+        self._sig = hash((self._sig if self._pending else 0, x.data_ptr(), tuple(x.shape), tuple(x.stride()), x.dtype, batch))
         self._pending.append((x, batch))
         _DIRTY[id(self)] = self
         self.nsamples += batch
@@ -446,6 +509,7 @@ class GPTQ:
         if lut_quant or non_linear_quant or columnwise:
             raise NotImplementedError("lut_quant / non_linear_quant / columnwise are fork experiments outside "
                                       "the MI355X hot-path scope")
+        flush_pending()
         state = self._solve_enqueue(blocksize, percdamp, groupsize, actorder, static_groups)
         self._solve_finish(state)
 
@@ -456,7 +520,8 @@ class GPTQ:
         if int(q.maxq) < 0:
             raise NotImplementedError("trits are outside the MI355X hot-path scope")
         tick = time.time()
-        self._flush()
+        if self._pending:                # (fasterquant_many folds deferred inputs lane by lane)
+            _launch_flush([self._leader or self])
         self._materialize()              # shared running Hessian: this object's own copy ...
         self._release_followers()        # ... and the copies of those that share this one's
         W = self.layer.weight.data.clone()
@@ -539,6 +604,7 @@ class GPTQ:
         self._H = None
         self._pending = []
         _DIRTY.pop(id(self), None)
+        _LIVE.discard(self)
         self.Hinv = None
         self.codes = None
         self.Losses = None

@@ -73,6 +73,12 @@ int gptq_hessian_accum_mixed(int n_prob, float* const* H, const int* ldh, const 
                              int x_dtype, const int* ldx, const int* C, int tokens_each,
                              const int* nsamples_before, int batch_total, gptq_stream_t stream);
 
+/* Work decomposition hint for the following gptq_hessian_accum* calls of this host thread: size the launches for at
+ * most n_cu compute units (0 = the whole device), i.e. never more than n_cu workgroups in flight (every tile is then
+ * cut along K into n_cu runs).  For Hessian updates that run on a stream beside latency-bound work of other streams
+ * (the solves of other Linears), which needs free compute units to make progress. */
+int gptq_hessian_cu_limit(int n_cu);
+
 /* Mirror the upper triangle of A [n, n] into the lower triangle. */
 int gptq_symmetrize(float* A, int lda, int n, gptq_stream_t stream);
 

@@ -789,8 +789,10 @@ def test_hessian_grouped_problems_single_launch(G, O, hip_device):
     gen = torch.Generator().manual_seed(31)
     C, S, n = 256, 128, 5
     old = gmod.HESSIAN_DEFER
+    old_lazy = gmod.LAZY_HESSIANS
     try:
         gmod.HESSIAN_DEFER = 4
+        gmod.LAZY_HESSIANS = False           # every object folds its inputs when the batch is full
         solvers = [G.GPTQ(make_linear(torch.zeros(4, C, device=hip_device))) for _ in range(3)]
         other = G.GPTQ(make_linear(torch.zeros(4, 384, device=hip_device)))      # different in_features: own launch
         refs = [torch.zeros(C, C) for _ in range(3)]
@@ -812,7 +814,48 @@ def test_hessian_grouped_problems_single_launch(G, O, hip_device):
         assert any(cs == [C, C, C] for (cs, nslab, _, _) in launches)   # the three went out together
     finally:
         gmod.HESSIAN_DEFER = old
+        gmod.LAZY_HESSIANS = old_lazy
         gmod.FLUSH_EVENTS = None
+
+
+def test_lazy_hessians_fold_narrow_linears_beside_the_solve(G):
+    """LAZY_HESSIANS: while the hooks fire only the widest Linear folds its inputs; the narrow ones keep theirs and
+    fasterquant_many folds them on the side lanes.  Results must equal the eager run's up to the rounding of a
+    differently batched running mean (codes compared with a small mismatch allowance)."""
+    gm = G.gptq
+    gm.VERBOSE = False
+    old = (gm.HESSIAN_DEFER, gm.LAZY_HESSIANS)
+    try:
+        out = {}
+        for lazy in (False, True):
+            gm.HESSIAN_DEFER, gm.LAZY_HESSIANS = 2, lazy
+            g2 = torch.Generator().manual_seed(41)
+            shapes = [(64, 256), (64, 256), (128, 256), (96, 1024)]          # three narrow (two share inputs), one wide
+            objs = []
+            for (R, C) in shapes:
+                gp = G.GPTQ(make_linear((torch.randn(R, C, generator=g2) * 0.02).half().cuda()))
+                gp.quantizer = G.Quantizer(); gp.quantizer.configure(4, perchannel=True, sym=False, mse=False)
+                objs.append(gp)
+            gm.FLUSH_EVENTS = []
+            for _ in range(7):
+                xa = (torch.randn(1, 192, 256, generator=g2) * (1 + torch.arange(256) % 5)).half().cuda()
+                xb = (torch.randn(1, 192, 256, generator=g2) * (1 + torch.arange(256) % 3)).half().cuda()
+                xw = (torch.randn(1, 192, 1024, generator=g2) * (1 + torch.arange(1024) % 7)).half().cuda()
+                objs[0].add_batch(xa, None); objs[1].add_batch(xa, None); objs[2].add_batch(xb, None)
+                objs[3].add_batch(xw, None)
+            during = [cs for (cs, nslab, _, _) in gm.FLUSH_EVENTS]
+            gm.FLUSH_EVENTS = None
+            if lazy:
+                assert all(cs == [1024] for cs in during) and during          # only the wide one folded so far
+                assert len(objs[0]._pending) == 7 and len(objs[3]._pending) <= 2
+            G.fasterquant_many(objs, blocksize=128, percdamp=0.01, groupsize=128)
+            out[lazy] = [(o.codes.clone(), o.error) for o in objs]
+        for (ca, ea), (cb, eb) in zip(out[False], out[True]):
+            assert float((ca != cb).float().mean()) <= 2e-3
+            assert abs(ea - eb) <= 1e-2 * abs(ea)
+    finally:
+        gm.HESSIAN_DEFER, gm.LAZY_HESSIANS = old
+        gm.FLUSH_EVENTS = None
 
 
 def test_hessians_of_different_widths_in_one_flush(G):
