@@ -68,7 +68,7 @@ JOINT_SOLVE = True
 # solve's small kernels always find free ones.
 LAZY_HESSIANS = True
 LAZY_MAX_BYTES = 16 << 30
-LAZY_CUS = 96
+LAZY_CUS = int(__import__('os').environ.get('GPTQ_LAZY_CUS', '96'))
 
 
 def _input_signature(o):
