@@ -64,11 +64,11 @@ JOINT_SOLVE = True
 # When add_batch reaches HESSIAN_DEFER, fold only the widest Linears' inputs (their Hessians are the bulk of the flops
 # and sit on the critical path of the block); the narrower ones keep collecting inputs -- references, no copies, up to
 # LAZY_MAX_BYTES -- and fasterquant_many folds them on the side lanes, beside the widest Linear's solve, which is
-# latency-bound and leaves the chip idle.  Their launches are sized for LAZY_CUS compute units per lane so that the
-# solve's small kernels always find free ones.
+# latency-bound and leaves the chip idle.  They go out as one grouped flush sized for LAZY_CUS compute units, so that the
+# solve's small kernels always find free ones (measured: 32-96 CUs 37.9 ms per block, 128-256 CUs 38.6-40.0 ms).
 LAZY_HESSIANS = True
 LAZY_MAX_BYTES = 16 << 30
-LAZY_CUS = int(__import__('os').environ.get('GPTQ_LAZY_CUS', '96'))
+LAZY_CUS = int(__import__('os').environ.get('GPTQ_LAZY_CUS', '64'))   # 0 = no limit
 
 
 def _input_signature(o):
@@ -242,25 +242,47 @@ def fasterquant_many(solvers, blocksize=128, percdamp=.01, groupsize=-1, actorde
                 lane_ev = [[torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), 0.0] for _ in lanes]
                 for st, le in zip(lanes, lane_ev):
                     le[0].record(st)
+            placed = []                              # (unit, lane index), widest first
             for g in order:
                 k = min(range(want), key=lambda j: (load[j], j))
                 load[k] += cost(g)
+                placed.append((g, k))
+            owner = lambda g: g.members[0] if isinstance(g, _JointSolve) else g
+            # deferred Hessian updates of the units on the side lanes: ONE grouped flush on the first side lane (their
+            # launches are small; together they fill the chip better), the other side lanes wait for it
+            late = [owner(g) for g, k in placed if k > 0 and owner(g)._pending]
+            late_done = None
+
+            def flush_late():
+                nonlocal late_done
+                if not late or late_done is not None:
+                    return
+                st1 = lanes[1]
+                with torch.cuda.stream(st1):
+                    for o in late:
+                        for x, _ in o._pending:              # inputs were allocated on the caller's stream
+                            x.record_stream(st1)
+                    _lib.call("gptq_hessian_cu_limit", int(LAZY_CUS))
+                    try:
+                        _launch_flush(late)
+                    finally:
+                        _lib.call("gptq_hessian_cu_limit", 0)
+                    late_done = torch.cuda.Event()
+                    late_done.record(st1)
+                for st in lanes[2:]:
+                    st.wait_event(late_done)
+
+            for g, k in placed:
                 st = lanes[k]
                 if st is not cur and g._H is not None:
                     g._H.record_stream(st)
                 t_host = time.perf_counter()
+                if k > 0:
+                    flush_late()                     # (enqueued after the widest solve went out on the caller's stream)
                 with torch.cuda.stream(st):
-                    own = g.members[0] if isinstance(g, _JointSolve) else g
-                    if own._pending:                 # deferred Hessian updates: on this lane, beside the other solves
-                        beside = st is not cur and len(order) > 1
-                        if st is not cur:
-                            for x, _ in own._pending:        # inputs were allocated on the caller's stream
-                                x.record_stream(st)
-                        _lib.call("gptq_hessian_cu_limit", int(LAZY_CUS) if beside else 0)
-                        try:
-                            _launch_flush([own])
-                        finally:
-                            _lib.call("gptq_hessian_cu_limit", 0)
+                    own = owner(g)
+                    if own._pending:                 # the caller's-stream units fold their own, at full width
+                        _launch_flush([own])
                     mine.append((g, g._solve_enqueue(blocksize, percdamp, groupsize, actorder, static_groups)))
                 if LANE_EVENTS is not None:
                     lane_ev[k][2] += time.perf_counter() - t_host
