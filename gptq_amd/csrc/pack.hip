@@ -38,7 +38,7 @@ template <typename T, int BITS, int SRC>
 __global__ __launch_bounds__(256) void pack_kernel(const T* __restrict__ src, int lds_, int n_out, int n_in,
                                                    const float* __restrict__ scales,
                                                    const float* __restrict__ zeros,
-                                                   int32_t* __restrict__ qweight) {
+                                                   int32_t* __restrict__ qweight, bool vec4) {
   __shared__ uint32_t cs[PT_O][PT_I + 1];
   const int tid = threadIdx.x;
   const int o0 = blockIdx.y * PT_O, i0 = blockIdx.x * PT_I;
@@ -51,6 +51,12 @@ __global__ __launch_bounds__(256) void pack_kernel(const T* __restrict__ src, in
     const int o = o0 + ol;
     float s = 1.f, zs = 0.f;
     if (SRC == 0 && o < n_out) { s = scales[o]; zs = zeros[o]; }
+    if (SRC == 1 && vec4 && o < n_out && i0 + il + 3 < n_in) {  // four codes in one 32-bit load
+      const uint32_t q = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(src) + (long)o * lds_ + i0 + il);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cs[ol][il + e] = (q >> (8 * e)) & 0xffu;
+      continue;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int i = i0 + il + e;
@@ -94,8 +100,10 @@ template <typename T, int SRC>
 static int launch_pack(const T* src, int ld, int n_out, int n_in, const float* scales, const float* zeros,
                        int bits, int32_t* qweight, hipStream_t s) {
   const dim3 grid(cdiv(n_in, PT_I), cdiv(n_out, PT_O));
-  if (bits == 3) pack_kernel<T, 3, SRC><<<grid, 256, 0, s>>>(src, ld, n_out, n_in, scales, zeros, qweight);
-  else pack_kernel<T, 4, SRC><<<grid, 256, 0, s>>>(src, ld, n_out, n_in, scales, zeros, qweight);
+  // uint8 codes: 32-bit loads when every row starts 4-byte aligned
+  const bool vec4 = SRC == 1 && ld % 4 == 0 && reinterpret_cast<uintptr_t>(src) % 4 == 0;
+  if (bits == 3) pack_kernel<T, 3, SRC><<<grid, 256, 0, s>>>(src, ld, n_out, n_in, scales, zeros, qweight, vec4);
+  else pack_kernel<T, 4, SRC><<<grid, 256, 0, s>>>(src, ld, n_out, n_in, scales, zeros, qweight, vec4);
   GPTQ_CHECK_LAUNCH("pack_kernel");
   return GPTQ_OK;
 }
