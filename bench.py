@@ -67,6 +67,11 @@ def parse():
 
 def main():
     args = parse()
+    # stdout carries exactly one JSON line: everything libraries print there meanwhile (RCCL announces its version on
+    # stdout when the first communicator is created) is sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -262,7 +267,9 @@ def main():
         out["phases"]["solve_only_mparams_per_s"] = round(rank_params / (solve_ms / 1e3) / 1e6, 1) if solve_ms > 0 else None
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_samples)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        with os.fdopen(json_fd, "w") as real_stdout:
+            real_stdout.write(json.dumps(out) + "\n")
     if world > 1:
         dist.destroy_process_group()
 
