@@ -253,8 +253,8 @@ def main():
         if os.path.exists(pmc) and shape_cs == [8192] and per_launch == 8:
             traffic = json.load(open(pmc))["hbm_bytes_per_launch"]      # FETCH_SIZE x2 (gfx950) + WRITE_SIZE
         out["roofline"] = {
-            "kernel": "hessian16_big_kernel<f16> + hessian16_big_fixup (v_mfma_f32_32x32x16_f16 SYRK, 256x256 upper-triangle "
-                      "tiles, K-split last round, fp32 accumulate)",
+            "kernel": "hessian16_big16_kernel<f16> + hessian16_big16_fixup (v_mfma_f32_16x16x32_f16 SYRK, 256x256 upper-triangle "
+                      "tiles, K-split last round, fp32 accumulate; GPTQ_HESS_SHAPE=32 selects the 32x32x16 variant)",
             "launch_shape": f"Hessians of C = {sorted(shape_cs, reverse=True)} in one launch, {per_launch} samples x {SEQLEN} tokens each", "bound": "mfma",
             "achieved": round(achieved, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4), "traffic": traffic,

@@ -685,9 +685,10 @@ __global__ __launch_bounds__(64) void hessian16_big_fixup(ProbGroup pg, BigPlan 
 }
 
 // ---------------------------------------------------------------------------------------------
-// The same 256 x 256 tile on v_mfma_f32_16x16x32_{f16,bf16} (GPTQ_HESS_SHAPE=16).  Cycles per flop are those of
-// the 32x32x16 form; which of the two the chip clocks higher under load is an empirical matter
-// (MI355X_MICROARCH.md "DVFS give-back" item 7), so both are built on the same tile and work split.
+// The same 256 x 256 tile on v_mfma_f32_16x16x32_{f16,bf16} -- the DEFAULT whenever a segment has an even number of
+// stages (GPTQ_HESS_SHAPE=32 selects the 32x32x16 kernel above).  Cycles per flop are those of the 32x32x16 form;
+// which of the two the chip clocks higher under load is an empirical matter (MI355X_MICROARCH.md "DVFS give-back"
+// item 7), so both are built on the same tile and work split: this one measures 1.5-3 % faster in the bench.
 // One k-step is a whole 32-token stage: A fragment of block t = channels 16t..16t+15 x tokens 8g..8g+7 for lane
 // group g = lane >> 4, i.e. two transposed reads (token rows 8g + q and 8g + 4 + q).  The two groups of a
 // half-wave read rows 8 apart in the same columns, so the image also XORs chunk bit 1 with token-row bit 3:
@@ -1018,7 +1019,7 @@ static int hessian_launch_big(const HostProb* probs, int n_prob, int n_x, int x_
       }
       for (int p = np; p <= MAX_PROB; ++p) pg.tile_start[p] = total;
       const int nk_all = tokens / BBK * nx;
-      static const int shape_env = [] { const char* e = getenv("GPTQ_HESS_SHAPE"); return e ? atoi(e) : 32; }();
+      static const int shape_env = [] { const char* e = getenv("GPTQ_HESS_SHAPE"); return e ? atoi(e) : 16; }();
       const bool shape16 = shape_env == 16 && nk_all % 2 == 0;
       BigPlan plan{total, 0, 0, 1, nullptr};   // dp_tiles, left_tiles, workers, chunk, ws
       const int full = total / n_cu * n_cu, left = total - full;

@@ -4,7 +4,7 @@ FETCH_SIZE and WRITE_SIZE are in KiB-like units of 1 KB, collected in SEPARATE -
 FETCH_SIZE counts 64-B requests as 32 B, so the fetched bytes are doubled).
 
     python3 tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> \
-            [--kernels hessian16_big_kernel,hessian16_big_fixup] [--launch-of hessian16_big_kernel] [--shape "..."]
+            [--kernels hessian16_big16_kernel,hessian16_big16_fixup] [--launch-of hessian16_big16_kernel] [--shape "..."]
 Counters of all `--kernels` dispatches are summed and divided by the number of `--launch-of` dispatches
 (one Hessian update = one big kernel + its fixup), skipping the first (warm-up) launch."""
 import argparse
@@ -37,8 +37,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("fetch_csv")
 ap.add_argument("write_csv")
 ap.add_argument("out")
-ap.add_argument("--kernels", default="hessian16_big_kernel,hessian16_big_fixup")
-ap.add_argument("--launch-of", default="hessian16_big_kernel")
+ap.add_argument("--kernels", default="hessian16_big16_kernel,hessian16_big16_fixup")
+ap.add_argument("--launch-of", default="hessian16_big16_kernel")
 ap.add_argument("--shape", default="C=8192, S=2048 tokens x 8 samples per launch, fp16")
 ap.add_argument("--algorithmic-bytes", type=float, default=8 * 2048 * 8192 * 2 + 2 * 8192 * 8192 * 4 / 2)
 a = ap.parse_args()
