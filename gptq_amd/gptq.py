@@ -66,6 +66,7 @@ JOINT_SOLVE = True
 # LAZY_MAX_BYTES -- and fasterquant_many folds them on the side lanes, beside the widest Linear's solve, which is
 # latency-bound and leaves the chip idle.  They go out as one grouped flush sized for LAZY_CUS compute units, so that the
 # solve's small kernels always find free ones (measured: 32-96 CUs 37.9 ms per block, 128-256 CUs 38.6-40.0 ms).
+# Only in effect when HESSIAN_DEFER > 1 (the caller already opted into keeping hook inputs for a while).
 LAZY_HESSIANS = True
 LAZY_MAX_BYTES = 16 << 30
 LAZY_CUS = int(__import__('os').environ.get('GPTQ_LAZY_CUS', '64'))   # 0 = no limit
@@ -507,7 +508,7 @@ class GPTQ:
         if len(self._pending) >= max(1, int(HESSIAN_DEFER)):
             # this object is about to exceed the batch: its lock-step peers (the other Linears hooked in
             # the same forward passes) hold exactly as many inputs, so everything goes out grouped by shape
-            if not LAZY_HESSIANS:
+            if not LAZY_HESSIANS or int(HESSIAN_DEFER) <= 1:    # defer 1 = fold every call at once, like the reference
                 flush_pending()
             elif 2 * self.columns >= _widest_live():          # one of the widest Linears being calibrated
                 flush_pending(heavy_only=True)
