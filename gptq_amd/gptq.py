@@ -302,6 +302,74 @@ def fasterquant_many(solvers, blocksize=128, percdamp=.01, groupsize=-1, actorde
         g._solve_finish(state)
 
 
+def _enqueue_rows(dev, W, H, quantizer, preset_grid, blocksize, percdamp, groupsize, actorder, static_groups):
+    """Enqueue one gptq_fasterquant_rows call on the CURRENT stream for the rows of `W` [R, C] (fp32, contiguous) with
+    the Hessian `H` (consumed: left holding U); nothing here waits for the GPU.  `preset_grid` = (scale, zero) of a
+    ready quantizer (gptq.py:181) or None.  Returns the buffers of the call."""
+    q = quantizer
+    tick = time.time()
+    bits = int(getattr(q, "wbits", 0)) or (int(q.maxq) + 1).bit_length() - 1
+    R, C = W.shape
+    G = -(-C // groupsize) if groupsize > 0 else 0
+    scale = torch.zeros(R, device=dev, dtype=torch.float32)
+    zero = torch.zeros(R, device=dev, dtype=torch.float32)
+    if preset_grid is not None:
+        scale.copy_(preset_grid[0].reshape(-1))
+        zero.copy_(preset_grid[1].reshape(-1))
+    gscale = torch.empty((R, G), device=dev, dtype=torch.float32) if G else None
+    gzero = torch.empty((R, G), device=dev, dtype=torch.float32) if G else None
+    perm = torch.empty(C, device=dev, dtype=torch.int32) if actorder else None
+    codes = torch.empty((R, C), device=dev, dtype=torch.uint8)
+    stat = torch.zeros(2, device=dev, dtype=torch.float32)          # [error, info (int32 bits)]
+    row_loss = torch.empty(R, device=dev, dtype=torch.float32)
+    info = stat[1:].view(torch.int32)
+    lib = _lib.load()
+    nbytes = lib.gptq_fasterquant_workspace_bytes(R, C, int(blocksize), int(groupsize), int(bool(actorder)),
+                                                  int(bool(static_groups)))
+    ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    with torch.cuda.device(dev):
+        _lib.call("gptq_fasterquant_rows", _lib.ptr(W), W.stride(0), _lib.ptr(H), H.stride(0), R, C, bits,
+                  int(bool(q.sym)), int(blocksize), float(percdamp), int(groupsize), int(bool(actorder)),
+                  int(bool(static_groups)), _lib.ptr(scale), _lib.ptr(zero), int(preset_grid is not None),
+                  _lib.ptr(gscale), _lib.ptr(gzero), _lib.ptr(perm), _lib.ptr(codes), _lib.ptr(stat),
+                  _lib.ptr(row_loss), _lib.ptr(info), _lib.ptr(ws), nbytes, _lib.stream(dev))
+    return dict(tick=tick, W=W, H=H, scale=scale, zero=zero, gscale=gscale, gzero=gzero, perm=perm, codes=codes,
+                stat=stat, ws=ws, row_loss=row_loss, static_groups=bool(static_groups))
+
+
+def _check_solved(st):
+    """Wait for the solve (one sync, like torch.cuda.synchronize() at gptq.py:292); returns its `error` scalar."""
+    host = st["stat"].cpu()
+    bad = int(host[1:].view(torch.int32).item())
+    if bad:
+        raise torch.linalg.LinAlgError(
+            f"fasterquant: the damped Hessian is not positive-definite (pivot {bad}); cf. torch.linalg.cholesky")
+    return float(host[0].item())
+
+
+def _publish_rows(obj, st, a, b, error):
+    """Rows [a, b) of a finished solve become the results of `obj` (what callers read back, gptq.py:213, 305, plus
+    what packing grouped models needs)."""
+    q = obj.quantizer
+    obj.error = error
+    if VERBOSE:
+        print('time %.2f' % (time.time() - st["tick"]))
+        print('error', obj.error)
+    q.maxq = q.maxq.to(obj.dev)
+    q.scale = st["scale"][a:b].reshape(-1, 1)
+    q.zero = st["zero"][a:b].reshape(-1, 1)
+    obj.Hinv = st["H"]
+    obj.codes = st["codes"][a:b]
+    obj.group_scale = st["gscale"][a:b] if st["gscale"] is not None else None
+    obj.group_zero = st["gzero"][a:b] if st["gzero"] is not None else None
+    obj.perm = st["perm"]
+    obj.static_groups = st["static_groups"]
+    Q = st["W"][a:b]
+    if _Conv1D and isinstance(obj.layer, _Conv1D):
+        Q = Q.t()
+    obj.layer.weight.data = Q.reshape(obj.layer.weight.shape).to(obj.layer.weight.data.dtype)
+
+
 class _JointSolve:
     """GPTQ objects sharing one running Hessian, solved as one Linear whose rows are theirs stacked (leader first)."""
 
@@ -342,68 +410,25 @@ class _JointSolve:
 
     def _solve_enqueue(self, blocksize, percdamp, groupsize, actorder, static_groups):
         L = self.members[0]
-        q = L.quantizer
-        bits = int(getattr(q, "wbits", 0)) or (int(q.maxq) + 1).bit_length() - 1
-        tick = time.time()
         W = torch.cat([m.layer.weight.data.float() for m in self.members], 0).contiguous()
-        R, C = W.shape
-        dev = self.dev
         H = L._H
         for m in self.members:
             m._applied = m.nsamples if m.nsamples else m._applied
             m._H = None                  # consumed (gptq.py:141-142)
-        G = -(-C // groupsize) if groupsize > 0 else 0
-        scale = torch.zeros(R, device=dev, dtype=torch.float32)
-        zero = torch.zeros(R, device=dev, dtype=torch.float32)
-        gscale = torch.empty((R, G), device=dev, dtype=torch.float32) if G else None
-        gzero = torch.empty((R, G), device=dev, dtype=torch.float32) if G else None
-        perm = torch.empty(C, device=dev, dtype=torch.int32) if actorder else None
-        codes = torch.empty((R, C), device=dev, dtype=torch.uint8)
-        stat = torch.zeros(2, device=dev, dtype=torch.float32)
-        row_loss = torch.empty(R, device=dev, dtype=torch.float32)
-        info = stat[1:].view(torch.int32)
-        lib = _lib.load()
-        nbytes = lib.gptq_fasterquant_workspace_bytes(R, C, int(blocksize), int(groupsize), int(bool(actorder)),
-                                                      int(bool(static_groups)))
-        ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
-        with torch.cuda.device(dev):
-            _lib.call("gptq_fasterquant_rows", _lib.ptr(W), W.stride(0), _lib.ptr(H), H.stride(0), R, C, bits,
-                      int(bool(q.sym)), int(blocksize), float(percdamp), int(groupsize), int(bool(actorder)),
-                      int(bool(static_groups)), _lib.ptr(scale), _lib.ptr(zero), 0, _lib.ptr(gscale),
-                      _lib.ptr(gzero), _lib.ptr(perm), _lib.ptr(codes), _lib.ptr(stat), _lib.ptr(row_loss),
-                      _lib.ptr(info), _lib.ptr(ws), nbytes, _lib.stream(dev))
-            bounds, r0 = [], 0
-            for m in self.members:
-                bounds.append((r0, r0 + m.rows))
-                r0 += m.rows
-            errors = torch.stack([row_loss[a:b].sum() for a, b in bounds])
-        return dict(tick=tick, W=W, H=H, scale=scale, zero=zero, gscale=gscale, gzero=gzero, perm=perm, codes=codes,
-                    stat=stat, ws=ws, row_loss=row_loss, errors=errors, bounds=bounds,
-                    static_groups=bool(static_groups))
+        st = _enqueue_rows(self.dev, W, H, L.quantizer, None, blocksize, percdamp, groupsize, actorder, static_groups)
+        bounds, r0 = [], 0
+        for m in self.members:
+            bounds.append((r0, r0 + m.rows))
+            r0 += m.rows
+        st["bounds"] = bounds
+        st["errors"] = torch.stack([st["row_loss"][a:b].sum() for a, b in bounds])   # each member's own sum(Losses)
+        return st
 
     def _solve_finish(self, st):
-        host = st["stat"].cpu()
-        bad = int(host[1:].view(torch.int32).item())
-        if bad:
-            raise torch.linalg.LinAlgError(
-                f"fasterquant: the damped Hessian is not positive-definite (pivot {bad}); cf. torch.linalg.cholesky")
+        _check_solved(st)
         errors = st["errors"].cpu()
         for m, (a, b), err in zip(self.members, st["bounds"], errors):
-            q = m.quantizer
-            m.error = float(err.item())
-            if VERBOSE:
-                print('time %.2f' % (time.time() - st["tick"]))
-                print('error', m.error)
-            q.maxq = q.maxq.to(self.dev)
-            q.scale = st["scale"][a:b].reshape(-1, 1)
-            q.zero = st["zero"][a:b].reshape(-1, 1)
-            m.Hinv = st["H"]
-            m.codes = st["codes"][a:b]
-            m.group_scale = st["gscale"][a:b] if st["gscale"] is not None else None
-            m.group_zero = st["gzero"][a:b] if st["gzero"] is not None else None
-            m.perm = st["perm"]
-            m.static_groups = st["static_groups"]
-            m.layer.weight.data = st["W"][a:b].reshape(m.layer.weight.shape).to(m.layer.weight.data.dtype)
+            _publish_rows(m, st, a, b, float(err.item()))
 
 
 class GPTQ:
@@ -539,10 +564,8 @@ class GPTQ:
     def _solve_enqueue(self, blocksize, percdamp, groupsize, actorder, static_groups):
         """Enqueue the whole solve on the CURRENT stream; nothing here waits for the GPU."""
         q = self.quantizer
-        bits = int(getattr(q, "wbits", 0)) or (int(q.maxq) + 1).bit_length() - 1
         if int(q.maxq) < 0:
             raise NotImplementedError("trits are outside the MI355X hot-path scope")
-        tick = time.time()
         if self._pending:                # (fasterquant_many folds deferred inputs lane by lane)
             _launch_flush([self._leader or self])
         self._materialize()              # shared running Hessian: this object's own copy ...
@@ -553,68 +576,17 @@ class GPTQ:
         if _Conv1D and isinstance(self.layer, _Conv1D):
             W = W.t()
         W = W.float().contiguous()
-        R, C = W.shape
-        dev = self.dev
-
         self._applied = self.nsamples if self.nsamples else self._applied
         H = self._H                      # upper triangle is all the solver reads
         self._H = None                   # consumed, like `del self.H` (gptq.py:141-142)
         if H is None:
             raise RuntimeError("fasterquant: H was already consumed or freed")
-        G = -(-C // groupsize) if groupsize > 0 else 0
-        scale = torch.zeros(R, device=dev, dtype=torch.float32)
-        zero = torch.zeros(R, device=dev, dtype=torch.float32)
-        preset = 0
-        if q.scale.numel() == R and bool(q.ready()):          # gptq.py:181
-            scale.copy_(q.scale.reshape(-1))
-            zero.copy_(q.zero.reshape(-1))
-            preset = 1
-        gscale = torch.empty((R, G), device=dev, dtype=torch.float32) if G else None
-        gzero = torch.empty((R, G), device=dev, dtype=torch.float32) if G else None
-        perm = torch.empty(C, device=dev, dtype=torch.int32) if actorder else None
-        codes = torch.empty((R, C), device=dev, dtype=torch.uint8)
-        stat = torch.zeros(2, device=dev, dtype=torch.float32)          # [error, info (int32 bits)]
-        info = stat[1:].view(torch.int32)
-        lib = _lib.load()
-        nbytes = lib.gptq_fasterquant_workspace_bytes(R, C, int(blocksize), int(groupsize), int(bool(actorder)),
-                                                      int(bool(static_groups)))
-        ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
-        with torch.cuda.device(dev):
-            _lib.call("gptq_fasterquant", _lib.ptr(W), W.stride(0), _lib.ptr(H), H.stride(0), R, C, bits,
-                      int(bool(q.sym)), int(blocksize), float(percdamp), int(groupsize), int(bool(actorder)),
-                      int(bool(static_groups)), _lib.ptr(scale), _lib.ptr(zero), preset, _lib.ptr(gscale),
-                      _lib.ptr(gzero), _lib.ptr(perm), _lib.ptr(codes), _lib.ptr(stat), _lib.ptr(info),
-                      _lib.ptr(ws), nbytes, _lib.stream(dev))
-        return dict(tick=tick, W=W, H=H, scale=scale, zero=zero, gscale=gscale, gzero=gzero, perm=perm, codes=codes,
-                    stat=stat, ws=ws, static_groups=bool(static_groups))
+        preset = (q.scale, q.zero) if (q.scale.numel() == W.shape[0] and bool(q.ready())) else None   # gptq.py:181
+        return _enqueue_rows(self.dev, W, H, q, preset, blocksize, percdamp, groupsize, actorder, static_groups)
 
     def _solve_finish(self, st):
-        """Wait for the solve (one sync, like torch.cuda.synchronize() at gptq.py:292) and publish its results."""
-        q = self.quantizer
-        dev = self.dev
-        host = st["stat"].cpu()
-        bad = int(host[1:].view(torch.int32).item())
-        if bad:
-            raise torch.linalg.LinAlgError(
-                f"fasterquant: the damped Hessian is not positive-definite (pivot {bad}); cf. torch.linalg.cholesky")
-        self.error = float(host[0].item())
-        if VERBOSE:
-            print('time %.2f' % (time.time() - st["tick"]))
-            print('error', self.error)
-
-        # state the callers read back (gptq.py:213, 305) + what packing grouped models needs
-        q.maxq = q.maxq.to(dev)
-        q.scale = st["scale"].reshape(-1, 1)
-        q.zero = st["zero"].reshape(-1, 1)
-        self.Hinv = st["H"]
-        self.codes = st["codes"]
-        self.group_scale, self.group_zero = st["gscale"], st["gzero"]
-        self.perm = st["perm"]
-        self.static_groups = st["static_groups"]
-        Q = st["W"]
-        if _Conv1D and isinstance(self.layer, _Conv1D):
-            Q = Q.t()
-        self.layer.weight.data = Q.reshape(self.layer.weight.shape).to(self.layer.weight.data.dtype)
+        """Wait for the solve and publish its results."""
+        _publish_rows(self, st, 0, st["W"].shape[0], _check_solved(st))
 
     def free(self):
         if DEBUG:
