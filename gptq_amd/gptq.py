@@ -282,8 +282,12 @@ def fasterquant_many(solvers, blocksize=128, percdamp=.01, groupsize=-1, actorde
                     flush_late()                     # (enqueued after the widest solve went out on the caller's stream)
                 with torch.cuda.stream(st):
                     own = owner(g)
-                    if own._pending:                 # the caller's-stream units fold their own, at full width
+                    if own._pending:                 # the caller's-stream units fold their own, at full width ...
                         _launch_flush([own])
+                        if k == 0 and late and late_done is None and want > 1:
+                            wide_done = torch.cuda.Event()      # ... and the late updates start after them
+                            wide_done.record(st)
+                            lanes[1].wait_event(wide_done)
                     mine.append((g, g._solve_enqueue(blocksize, percdamp, groupsize, actorder, static_groups)))
                 if LANE_EVENTS is not None:
                     lane_ev[k][2] += time.perf_counter() - t_host
