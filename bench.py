@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--nsamples", type=int, default=128, help="calibration samples per step (reference default 128)")
-    ap.add_argument("--hessian-defer", type=int, default=8,
+    ap.add_argument("--hessian-defer", type=int, default=16,
                     help="hook inputs folded into H per launch (gptq_amd.gptq.HESSIAN_DEFER; 1 = per call like the reference)")
     ap.add_argument("--serial-solve", action="store_true", help="solve the Linears one by one instead of on concurrent streams")
     ap.add_argument("--no-lazy-hessians", action="store_true",
@@ -250,7 +250,7 @@ def main():
         achieved = flops_launch / (launch_ms / 1e3) / 1e12 if launch_ms > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_hessian16_big_pmc.json")   # tools/pmc_traffic.py, same launch shape
-        if os.path.exists(pmc) and shape_cs == [8192] and per_launch == 8:
+        if os.path.exists(pmc) and shape_cs == [8192] and per_launch == json.load(open(pmc)).get("samples_per_launch", 8):
             traffic = json.load(open(pmc))["hbm_bytes_per_launch"]      # FETCH_SIZE x2 (gfx950) + WRITE_SIZE
         out["roofline"] = {
             "kernel": "hessian16_big16_kernel<f16> + hessian16_big16_fixup (v_mfma_f32_16x16x32_f16 SYRK, 256x256 upper-triangle "

@@ -44,7 +44,7 @@ class QuantArgs:
     nsamples: int = 128
     nearest: bool = False
     blocksize: int = 128
-    hessian_defer: int = 8      # hook inputs folded into H per launch (gptq_amd.gptq.HESSIAN_DEFER)
+    hessian_defer: int = 16     # hook inputs folded into H per launch (gptq_amd.gptq.HESSIAN_DEFER)
     row_slabs: int = 1          # multi-GPU only, gptq_amd.parallel.plan_units: 0 never, 1 when ranks would idle, k >= 2 always
 
 

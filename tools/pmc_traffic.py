@@ -39,14 +39,15 @@ ap.add_argument("write_csv")
 ap.add_argument("out")
 ap.add_argument("--kernels", default="hessian16_big16_kernel,hessian16_big16_fixup")
 ap.add_argument("--launch-of", default="hessian16_big16_kernel")
-ap.add_argument("--shape", default="C=8192, S=2048 tokens x 8 samples per launch, fp16")
-ap.add_argument("--algorithmic-bytes", type=float, default=8 * 2048 * 8192 * 2 + 2 * 8192 * 8192 * 4 / 2)
+ap.add_argument("--samples", type=int, default=16, help="2048-token samples folded per launch (C = 8192)")
 a = ap.parse_args()
 ks = a.kernels.split(",")
 f, nf = collect(a.fetch_csv, "FETCH_SIZE", ks, a.launch_of)
 w, nw = collect(a.write_csv, "WRITE_SIZE", ks, a.launch_of)
+a.shape = f"C=8192, S=2048 tokens x {a.samples} samples per launch, fp16"
+a.algorithmic_bytes = a.samples * 2048 * 8192 * 2 + 2 * 8192 * 8192 * 4 / 2
 out = {
-    "kernels": ks, "shape": a.shape,
+    "kernels": ks, "shape": a.shape, "samples_per_launch": a.samples,
     "FETCH_SIZE_KB_per_launch": f / max(nf, 1), "FETCH_SIZE_launches": nf,
     "WRITE_SIZE_KB_per_launch": w / max(nw, 1), "WRITE_SIZE_launches": nw,
     "fetch_bytes_corrected_x2": 2 * 1024 * f / max(nf, 1),
