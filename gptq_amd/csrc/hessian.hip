@@ -498,7 +498,9 @@ __global__ __launch_bounds__(512) void hessian16_big_kernel(ProbGroup pg, BigPla
   const int dma_dst = img * BHALF + (16 * (wave & 1)) * 256;  // wave-uniform; the DMA adds lane * 16
 
   // this workgroup's segments: (tile, stages [s0, s1), partial slot or -1 for the direct epilogue)
-  const int bid = blockIdx.x;
+  // work items: [0, dp_tiles) whole tiles, then `workers` K-split runs; a launch sized for a CU budget has fewer
+  // workgroups than items and every workgroup strides over them
+  for (int bid = blockIdx.x; bid < plan.dp_tiles + plan.workers; bid += gridDim.x) {
   int run_begin = 0, run_end = 0;
   const bool whole = bid < plan.dp_tiles;
   if (!whole) {
@@ -628,6 +630,7 @@ __global__ __launch_bounds__(512) void hessian16_big_kernel(ProbGroup pg, BigPla
 #pragma unroll
           for (int e = 0; e < 16; ++e) part[big_part_index(wave, t, u, e, lane)] = acc[t][u][e];
     }
+  }
   }
 }
 
@@ -764,7 +767,9 @@ __global__ __launch_bounds__(512) void hessian16_big16_kernel(ProbGroup pg, BigP
   const int chunk_hi = chunk_lo ^ 2;                          // pieces 2, 3
   const int dma_dst = img * BHALF + (16 * (wave & 1)) * 256;
 
-  const int bid = blockIdx.x;
+  // work items: [0, dp_tiles) whole tiles, then `workers` K-split runs; a launch sized for a CU budget has fewer
+  // workgroups than items and every workgroup strides over them
+  for (int bid = blockIdx.x; bid < plan.dp_tiles + plan.workers; bid += gridDim.x) {
   int run_begin = 0, run_end = 0;
   const bool whole = bid < plan.dp_tiles;
   if (!whole) {
@@ -914,6 +919,7 @@ __global__ __launch_bounds__(512) void hessian16_big16_kernel(ProbGroup pg, BigP
           for (int e = 0; e < 4; ++e) part[big16_part_index(wave, t, u, e, lane)] = acc[t][u][e];
     }
   }
+  }
 }
 
 __global__ __launch_bounds__(512) void hessian16_big16_fixup(ProbGroup pg, BigPlan plan, int nk_all) {
@@ -1034,7 +1040,8 @@ static int hessian_launch_big(const HostProb* probs, int n_prob, int n_x, int x_
         GPTQ_CHECK_ARG(plan.ws != nullptr, "gptq_hessian_accum: cannot allocate the %zu-byte split-K workspace",
                        sizeof(float) * 2 * BTILE_FLOATS * (size_t)plan.workers);
       }
-      const int grid = plan.dp_tiles + plan.workers;
+      int grid = plan.dp_tiles + plan.workers;
+      if (g_cu_limit > 0) grid = std::min(grid, n_cu);            // a real budget: the workgroups stride over the items
 #define HBIG(BF, RG, AB)                                                                                      \
   do {                                                                                                        \
     const size_t lds_b = (size_t)(RG) * BSTAGE;                                                               \

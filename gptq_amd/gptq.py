@@ -65,11 +65,11 @@ JOINT_SOLVE = True
 # and sit on the critical path of the block); the narrower ones keep collecting inputs -- references, no copies, up to
 # LAZY_MAX_BYTES -- and fasterquant_many folds them on the side lanes, beside the widest Linear's solve, which is
 # latency-bound and leaves the chip idle.  They go out as one grouped flush sized for LAZY_CUS compute units, so that the
-# solve's small kernels always find free ones (measured: 32-96 CUs 37.9 ms per block, 128-256 CUs 38.6-40.0 ms).
+# solve's small kernels always find free ones (measured on one box: 32 CUs 44.6 ms per block, 64: 37.4, 80: 36.6, 96: 36.6, 128: 38.5, 192: 38.9).
 # Only in effect when HESSIAN_DEFER > 1 (the caller already opted into keeping hook inputs for a while).
 LAZY_HESSIANS = True
 LAZY_MAX_BYTES = 16 << 30
-LAZY_CUS = int(__import__('os').environ.get('GPTQ_LAZY_CUS', '64'))   # 0 = no limit
+LAZY_CUS = int(__import__('os').environ.get('GPTQ_LAZY_CUS', '80'))   # 0 = no limit
 
 
 def _input_signature(o):

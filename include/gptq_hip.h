@@ -74,10 +74,9 @@ int gptq_hessian_accum_mixed(int n_prob, float* const* H, const int* ldh, const 
                              const int* nsamples_before, int batch_total, gptq_stream_t stream);
 
 /* Work decomposition hint for the following gptq_hessian_accum* calls of this host thread: size the launches for at
- * most n_cu compute units (0 = the whole device): whole-K rounds of n_cu workgroups and a K-split last round of n_cu
- * runs (launches with fewer tiles than n_cu never have more than n_cu workgroups in flight).  For Hessian updates
- * that run on a stream beside latency-bound work of other streams (the solves of other Linears), which needs free
- * compute units to make progress. */
+ * most n_cu compute units (0 = the whole device): the 256x256-tile kernels then launch n_cu workgroups that stride
+ * over the whole-K tiles and the K-split runs.  For Hessian updates that run on a stream beside latency-bound work
+ * of other streams (the solves of other Linears), which needs free compute units to make progress. */
 int gptq_hessian_cu_limit(int n_cu);
 
 /* Mirror the upper triangle of A [n, n] into the lower triangle. */

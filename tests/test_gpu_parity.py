@@ -888,6 +888,7 @@ def test_hessians_of_different_widths_in_one_flush(G):
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"GPTQ_HESS_BIG": "2", "GPTQ_HESS_SHAPE": "32"},     # 256x256 tiles on 32x32x16 MFMAs
                                  {"GPTQ_HESS_BIG": "2", "GPTQ_HESS_SHAPE": "16"},     # ... on 16x16x32 MFMAs (the default)
+                                 {"GPTQ_HESS_BIG": "2", "GPTQ_CHECK_CU_LIMIT": "24"},  # CU budget: workgroups stride over the tiles
                                  {"GPTQ_HESS_BIG": "3"},                               # no K-split last round
                                  {"GPTQ_HESS_BIG": "0"}])                              # 128x128 tiles only
 def test_hessian_kernel_variants_in_subprocess(env):

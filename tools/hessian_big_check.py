@@ -115,6 +115,8 @@ def timeit(C, n_prob, n_x=8, tokens=2048, reps=5):
 
 
 args = sys.argv[1:]
+if os.environ.get("GPTQ_CHECK_CU_LIMIT"):            # size every launch for that many compute units
+    _lib.call("gptq_hessian_cu_limit", int(os.environ["GPTQ_CHECK_CU_LIMIT"]))
 print("GPTQ_HESS_BIG =", os.environ.get("GPTQ_HESS_BIG", "(default)"), "RING =", os.environ.get("GPTQ_HESS_RING", "-"),
       "ABLATE =", os.environ.get("GPTQ_HESS_ABLATE", "-"), flush=True)
 if "--time-only" in args:          # --time-only C:problems [C:problems ...]
