@@ -4,11 +4,16 @@
 A step = one pass of the GPTQ hot path over one OPT-1.3b decoder block's six Linears
 (q,k,v,out 2048x2048, fc1 8192x2048, fc2 2048x8192; 4-bit, groupsize 128, static groups as
 opt.py:584-587 forces), exactly as the reference drives it for one block (opt.py:177-214):
-  1. Hessian accumulation: nsamples x add_batch per Linear (one 2048-token sample per call, fp16);
-  2. fasterquant per Linear (damped inverse factor + column loop + trailing updates);
+  1. Hessian accumulation: nsamples x add_batch per Linear (one 2048-token sample per call, fp16), in the order the
+     reference's hooks fire; q/k/v are fed one tensor, as in the model (--no-shared-inputs: private tensors);
+  2. fasterquant of every Linear (damped inverse factor + column loop + trailing updates) through
+     gptq_amd.fasterquant_many (--serial-solve: one by one);
   3. 4-bit pack of the integer codes (the reference packs on the host; its own TODO, opt.py:361).
 Inputs (fp16 weights + fp16 calibration activations) are resident in HBM before the timed
-region.  value = params quantized by all ranks / max-over-ranks wall time.
+region.  value = params quantized by all ranks / max-over-ranks wall time.  All the work of 1-3 happens inside the
+timed region, but not always in that order on the GPU: add_batch defers hook inputs by reference (--hessian-defer per
+launch), and the narrow Linears' Hessian updates run beside the widest Linear's solve (--no-lazy-hessians: as the hooks
+fire); `phases` reports where the time went (the "hessian" phase then holds only what was folded while the hooks fired).
 
 N > 1 (one process per GPU, launched by torch.distributed.run): weak scaling -- the job is N
 blocks' worth of Linears dealt to ranks by cost (gptq_amd.parallel.assign_units); the only
