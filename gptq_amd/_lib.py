@@ -12,7 +12,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgptq_hip.so")
+# GPTQ_HIP_LIB: load another build of the same ABI (tools use it for the diagnostic library, gptq_amd.build --diag)
+LIB_PATH = os.environ.get("GPTQ_HIP_LIB") or os.path.join(_HERE, "libgptq_hip.so")
 
 F32, F16, BF16 = 0, 1, 2
 _DTYPES = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
@@ -24,8 +25,7 @@ _SIGNATURES = {
     "gptq_hessian_accum": (C.c_int, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
     "gptq_hessian_accum_multi": (C.c_int, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "gptq_hessian_accum_group": (C.c_int, [_i, _p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p]),
-    "gptq_hessian_accum_mixed": (C.c_int, [_i, _p, _p, _p, _i, _i, _p, _p, _i, _p, _i, _p]),
-    "gptq_hessian_cu_limit": (C.c_int, [_i]),
+    "gptq_hessian_accum_mixed": (C.c_int, [_i, _p, _p, _p, _i, _i, _p, _p, _i, _p, _i, _i, _p]),
     "gptq_symmetrize": (C.c_int, [_p, _i, _i, _p]),
     "gptq_find_params": (C.c_int, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _i, _p]),
     "gptq_quantize_rows": (C.c_int, [_p, _i, _i, _i, _p, _p, _i, _p]),
@@ -54,13 +54,21 @@ class GptqHipError(RuntimeError):
 
 
 def load() -> C.CDLL:
-    """Load the library (no GPU needed to load it).  Fails loudly if it was not built."""
+    """Load the library (no GPU needed to load it).  A clean checkout carries sources only (*.so is git-ignored):
+    when the library is missing and hipcc is present it is built in-tree first (about a minute, once);
+    without hipcc this fails loudly -- there is no non-HIP fallback."""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
-            raise GptqHipError(
-                f"{LIB_PATH} not found: build it with `python -m gptq_amd.build` (hipcc, gfx950). "
-                "gptq_amd has no non-HIP fallback.")
+            try:
+                from .build import build_library
+                build_library(verbose=False)
+            except Exception as e:
+                raise GptqHipError(
+                    f"{LIB_PATH} not found and building it failed ({e}); build it with `python -m gptq_amd.build` "
+                    "(hipcc, gfx950).  gptq_amd has no non-HIP fallback.") from e
+        if not os.path.exists(LIB_PATH):
+            raise GptqHipError(f"{LIB_PATH} not found: build it with `python -m gptq_amd.build` (hipcc, gfx950).")
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)

@@ -14,6 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgptq_hip.so")
+DIAG_LIB = os.path.join(HERE, "libgptq_hip_diag.so")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 SOURCES = ["core.cpp", "hessian.hip", "cholesky.hip", "fasterquant.hip", "pack.hip", "matvec.hip"]
 # -ffp-contract=off: the quantize / error-feedback chain must round exactly like the reference's
@@ -38,8 +39,13 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force: bool = False, verbose: bool = True) -> str:
+def build_library(force: bool = False, verbose: bool = True, diag: bool = False) -> str:
+    """diag=True builds libgptq_hip_diag.so instead: the same sources with -DGPTQ_DIAG, which compiles in the
+    timing-only ablation variants (GPTQ_*_ABLATE environment knobs; their results are WRONG by design).  The product
+    library never contains them; tools load the diagnostic one explicitly through GPTQ_HIP_LIB."""
     hipcc = _hipcc()
+    LIB = DIAG_LIB if diag else globals()["LIB"]
+    OBJ = globals()["OBJ"] + ("_diag" if diag else "")
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "gptq_hip.h"))
@@ -51,7 +57,8 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
         objs.append(o)
         if force or _stale(o, [s] + headers):
             lang = ["-x", "hip"] if src.endswith(".cpp") else []
-            jobs.append([hipcc] + FLAGS + PER_FILE_FLAGS.get(src, []) + lang + ["-c", s, "-o", o])
+            jobs.append([hipcc] + FLAGS + (["-DGPTQ_DIAG"] if diag else []) + PER_FILE_FLAGS.get(src, []) + lang
+                        + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -69,4 +76,4 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    print(build_library(force="--force" in sys.argv))
+    print(build_library(force="--force" in sys.argv, diag="--diag" in sys.argv))

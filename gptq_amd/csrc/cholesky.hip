@@ -59,122 +59,8 @@ __global__ __launch_bounds__(256) void build_abar_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
-// Diagonal block: L_kk = chol(A_kk) in LDS, then X = L_kk^-1 written to the diagonal block of Linv.
-// 512 threads.  Factorization: right-looking, two barriers per column.  Inverse: column-parallel
-// forward substitution, a quad of lanes per column (rows i = 4r + q), DPP quad broadcast, no barriers.
-// ---------------------------------------------------------------------------------------------
-template <int Q>
-__device__ __forceinline__ float quad_bcast(float v) {
-  return __builtin_bit_cast(
-      float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), Q * 0x55, 0xf, 0xf, true));
-}
-
-__global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__ A, float* __restrict__ Linv,
-                                                             int Cp, int kb, int32_t* __restrict__ info) {
-  constexpr int LD = NB + 1;
-  __shared__ float S[NB * LD];
-  __shared__ float rdiag[NB];
-  __shared__ float colbuf[2][NB];
-  const int tid = threadIdx.x;
-  float* Ak = A + (long)kb * NB * Cp + (long)kb * NB;
-
-  // ---- factorization, register resident: thread (iy = tid >> 5, kx = tid & 31) owns the elements
-  //      (i = iy + 16a, k = kx + 32b), a < 8, b < 4, of the lower triangle.  Per column j the owners
-  //      publish the raw column through LDS (double buffered -> ONE barrier per column), every thread
-  //      scales the entries it needs by 1/sqrt(a_jj) and applies its share of the rank-1 update.
-  const int kx = tid & 31, iy = tid >> 5;
-  float a[8][4];
-#pragma unroll
-  for (int aa = 0; aa < 8; ++aa)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int i = iy + 16 * aa, k = kx + 32 * b;
-      a[aa][b] = (k <= i) ? Ak[(long)i * Cp + k] : 0.f;
-    }
-  // Only the column operand is masked (k > j).  Elements strictly above the diagonal are never read
-  // back, so they may collect garbage; whole row / column groups that lie left of or above the
-  // current column are skipped statically (the j loop is unrolled over its 32-column phase bj).
-#pragma unroll
-  for (int bj = 0; bj < 4; ++bj) {
-#pragma unroll 1
-    for (int jl = 0; jl < 32; ++jl) {
-      const int j = 32 * bj + jl;
-      float* cb = colbuf[j & 1];
-      if (kx == jl) {
-#pragma unroll
-        for (int aa = 2 * bj; aa < 8; ++aa) cb[iy + 16 * aa] = a[aa][bj];
-      }
-      __syncthreads();
-      const float ajj = cb[j];
-      const float d = sqrtf(ajj);
-      const float inv = 1.f / d;
-      if (tid == 0) {
-        rdiag[j] = inv;
-        if (!(ajj > 0.f) && info) atomicCAS(info, 0, kb * NB + j + 1);
-      }
-      float li[8], lk[4];
-#pragma unroll
-      for (int aa = 2 * bj; aa < 8; ++aa) li[aa] = cb[iy + 16 * aa] * inv;
-#pragma unroll
-      for (int b = bj; b < 4; ++b) lk[b] = cb[kx + 32 * b] * inv;
-      if (kx <= jl) lk[bj] = 0.f;                                   // k <= j: column already final
-#pragma unroll
-      for (int aa = 2 * bj; aa < 8; ++aa) {
-#pragma unroll
-        for (int b = bj; b < 4; ++b) {
-          if (32 * b <= 16 * aa + 15) a[aa][b] -= li[aa] * lk[b];   // static: tile touches the lower triangle
-        }
-        if (kx == jl) {
-          const int i = iy + 16 * aa;
-          a[aa][bj] = (i > j) ? li[aa] : ((i == j) ? d : a[aa][bj]);   // column j is final
-        }
-      }
-    }
-  }
-  // L_kk -> LDS (for the inverse) and back to A (kept for inspection)
-#pragma unroll
-  for (int aa = 0; aa < 8; ++aa)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int i = iy + 16 * aa, k = kx + 32 * b;
-      S[i * LD + k] = (k <= i) ? a[aa][b] : 0.f;
-      if (k <= i) Ak[(long)i * Cp + k] = a[aa][b];
-    }
-  __syncthreads();
-
-  // ---- inverse: thread (c = tid >> 2, q = tid & 3) owns rows i = 4r + q of column c ----
-  const int c = tid >> 2, q = tid & 3;
-  float x[32];
-#pragma unroll
-  for (int r = 0; r < 32; ++r) x[r] = (4 * r + q == c) ? 1.f : 0.f;
-  const int c0 = (tid & ~63) >> 2;   // first column handled by this wave
-#pragma unroll
-  for (int jj = 0; jj < 32; ++jj) {
-    if (jj < (c0 >> 2)) continue;    // wave-uniform: rows above every column of the wave are zero
-#pragma unroll
-    for (int qq = 0; qq < 4; ++qq) {
-      const int j = 4 * jj + qq;
-      const float xr = (qq == 0) ? quad_bcast<0>(x[jj]) : (qq == 1) ? quad_bcast<1>(x[jj])
-                     : (qq == 2) ? quad_bcast<2>(x[jj]) : quad_bcast<3>(x[jj]);
-      const float xj = xr * rdiag[j];
-      if (q == qq) x[jj] = xj;
-#pragma unroll
-      for (int r = jj; r < 32; ++r) {
-        const int i = 4 * r + q;
-        if (i > j) x[r] -= S[i * LD + j] * xj;
-      }
-    }
-  }
-  float* Xk = Linv + (long)kb * NB * Cp + (long)kb * NB;
-#pragma unroll
-  for (int r = 0; r < 32; ++r) {
-    const int i = 4 * r + q;
-    Xk[(long)i * Cp + c] = (i >= c) ? x[r] : 0.f;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// v2 of the diagonal block kernel: hierarchical, 32-wide sub-blocks.
+// Diagonal block: L_kk = chol(A_kk) and X = L_kk^-1 (written to the diagonal block of Linv); hierarchical,
+// 32-wide sub-blocks.
 //   factorization, for s = 0..3:  (A1) wave 0 factors the 32x32 diagonal sub-block in REGISTERS (lane =
 //   row, v_readlane broadcasts, no barrier inside);  (A2) the sub-panel below is solved by per-row forward
 //   substitution (thread = row, L_D broadcast from LDS);  (A3) the remaining sub-blocks get their rank-32
@@ -498,17 +384,16 @@ extern "C" int gptq_hinv_upper(float* H, int ldh, int C, float percdamp, const i
   // updated on the caller's stream right after panel kb and the rest of the trailing SYRK runs on a helper
   // stream underneath them (they are serial and latency-bound).
   SideCtx* sc = (lookahead_mask() & 1) ? side_ctx(s) : nullptr;
-  bool side_busy = false, tri_on_side = false;
-  int tri_done[32] = {};                                         // pairs already launched, per level
-  static const int tri_overlap = [] { const char* e = getenv("GPTQ_TRTRI_OVERLAP"); return e ? atoi(e) : 0; }();
-  static const int potrf_v2 = [] { const char* e = getenv("GPTQ_POTRF_V2"); return e ? atoi(e) : 1; }();
+  bool side_busy = false;
+#ifdef GPTQ_DIAG   // timing-only ablation (wrong results): diagnostic library only
   static const int potrf_abl = [] { const char* e = getenv("GPTQ_POTRF_ABLATE"); return e ? atoi(e) : 0; }();
-  if (potrf_v2)
-    GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_inv_diag_v2_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_V2_LDS));
+#else
+  const int potrf_abl = 0;
+#endif
+  GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_inv_diag_v2_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_V2_LDS));
   for (int kb = 0; kb < nblk; ++kb) {
-    if (potrf_v2) potrf_inv_diag_v2_kernel<<<1, 512, POTRF_V2_LDS, s>>>(A, Linv, Cp, kb, info, potrf_abl);
-    else potrf_inv_diag_kernel<<<1, 512, 0, s>>>(A, Linv, Cp, kb, info);
+    potrf_inv_diag_v2_kernel<<<1, 512, POTRF_V2_LDS, s>>>(A, Linv, Cp, kb, info, potrf_abl);
     const int nrem = nblk - kb - 1;
     if (nrem <= 0) break;
     panel_kernel<<<nrem, GEMM_THREADS, 0, s>>>(A, Linv, Cp, kb);
@@ -524,35 +409,17 @@ extern "C" int gptq_hinv_upper(float* H, int ldh, int C, float percdamp, const i
       syrk_kernel<<<ntiles - nrem, GEMM_THREADS, 0, sc->stream>>>(A, Cp, kb, nrem, nrem);
       GPTQ_CHECK_HIP(hipEventRecord(sc->side_done, sc->stream));
       side_busy = true;
-      // Pairs of the recursive-doubling inverse whose blocks are all final (the pair at level sz ending at block
-      // kb) go out on the helper stream now, level by level, instead of after the whole factorization.
-      int lvl = 0;
-      for (int sz = 1; tri_overlap && sz < nblk; sz *= 2, ++lvl)
-        while ((tri_done[lvl] + 1) * 2 * sz <= kb + 1) {
-          trtri_step1_kernel<<<dim3(sz * sz, 1), GEMM_THREADS, 0, sc->stream>>>(A, Linv, Cp, nblk, sz, tri_done[lvl]);
-          trtri_step2_kernel<<<dim3(sz * sz, 1), GEMM_THREADS, 0, sc->stream>>>(Linv, Cp, nblk, sz, tri_done[lvl]);
-          ++tri_done[lvl];
-          tri_on_side = true;
-        }
     } else {
       if (side_busy) GPTQ_CHECK_HIP(hipStreamWaitEvent(s, sc->side_done, 0));
       syrk_kernel<<<ntiles, GEMM_THREADS, 0, s>>>(A, Cp, kb, nrem, 0);
       side_busy = false;
     }
   }
-  if (tri_on_side) {                                             // everything the helper stream still holds
-    GPTQ_CHECK_HIP(hipEventRecord(sc->side_done, sc->stream));
-    side_busy = true;
-  }
   if (side_busy) GPTQ_CHECK_HIP(hipStreamWaitEvent(s, sc->side_done, 0));
-  {
-    int lvl = 0;
-    for (int sz = 1; sz < nblk; sz *= 2, ++lvl) {
-      const int pairs = cdiv(nblk, 2 * sz), left = pairs - tri_done[lvl];
-      if (left <= 0) continue;
-      trtri_step1_kernel<<<dim3(sz * sz, left), GEMM_THREADS, 0, s>>>(A, Linv, Cp, nblk, sz, tri_done[lvl]);
-      trtri_step2_kernel<<<dim3(sz * sz, left), GEMM_THREADS, 0, s>>>(Linv, Cp, nblk, sz, tri_done[lvl]);
-    }
+  for (int sz = 1; sz < nblk; sz *= 2) {
+    const int pairs = cdiv(nblk, 2 * sz);
+    trtri_step1_kernel<<<dim3(sz * sz, pairs), GEMM_THREADS, 0, s>>>(A, Linv, Cp, nblk, sz, 0);
+    trtri_step2_kernel<<<dim3(sz * sz, pairs), GEMM_THREADS, 0, s>>>(Linv, Cp, nblk, sz, 0);
   }
   flip_to_upper_kernel<<<dim3(cdiv(C, 256), C), 256, 0, s>>>(Linv, Cp, C, H, ldh);
   GPTQ_CHECK_LAUNCH("gptq_hinv_upper");

@@ -70,5 +70,5 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace gptq
 
-extern "C" int gptq_hip_abi_version(void) { return 1; }
+extern "C" int gptq_hip_abi_version(void) { return 2; }
 extern "C" const char* gptq_last_error(void) { return gptq::g_err; }

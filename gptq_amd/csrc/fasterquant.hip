@@ -394,14 +394,16 @@ extern "C" int gptq_quantize_rows(float* X, int ldx, int R, int C, const float* 
 
 static int launch_quant_block(const QuantBlockArgs& a, int blocksize, bool grouped, hipStream_t s) {
   const int grid = cdiv(a.R, 64);
+#ifdef GPTQ_DIAG   // timing-only ablation builds (wrong results): diagnostic library only
   static const int abl = [] { const char* e = getenv("GPTQ_QB_ABLATE"); return e ? atoi(e) : 0; }();
-  if (abl && blocksize == 128 && grouped) {                      // diagnostic builds, timing only
+  if (abl && blocksize == 128 && grouped) {
     if (abl == 1) quant_block_kernel<4, true, 1><<<grid, 256, 0, s>>>(a);
     else if (abl == 2) quant_block_kernel<4, true, 2><<<grid, 256, 0, s>>>(a);
     else quant_block_kernel<4, true, 3><<<grid, 256, 0, s>>>(a);
     GPTQ_CHECK_LAUNCH("quant_block_kernel");
     return GPTQ_OK;
   }
+#endif
 #define QB_CASE(NPH)                                                                  \
   case 32 * NPH:                                                                      \
     if (grouped) quant_block_kernel<NPH, true><<<grid, 256, 0, s>>>(a);               \

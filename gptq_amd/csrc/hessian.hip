@@ -982,8 +982,6 @@ using namespace gptq;
 // One H update per problem; every problem brings `n_x` equally shaped slabs [tokens, C] (row-major, ldx).
 struct HostProb { float* H; const void* const* xs; float alpha, beta; int C, ldx, ldh; };
 
-static thread_local int g_cu_limit = 0;   // gptq_hessian_cu_limit
-
 // GPTQ_HESS_BIG: 0 = 128 x 128 kernel only, 1 = default, 2 = 256 x 256 kernel whenever the shapes allow,
 //                3 = like 2 but without the K-split last round
 static int hess_big_env() {
@@ -1000,12 +998,14 @@ static bool big_eligible(const HostProb& pr, int n_x, int x_dtype, int tokens) {
 }
 
 // 256 x 256 kernels: up to MAX_PROB problems per launch, of possibly different widths (all big_eligible).
-static int hessian_launch_big(const HostProb* probs, int n_prob, int n_x, int x_dtype, int tokens, hipStream_t s) {
+// cu_limit > 0: size the launch for at most that many compute units (the workgroups stride over the items).
+static int hessian_launch_big(const HostProb* probs, int n_prob, int n_x, int x_dtype, int tokens, int cu_limit,
+                              hipStream_t s) {
   const int big_env = hess_big_env();
   int dev = 0, n_cu = 256;
   GPTQ_CHECK_HIP(hipGetDevice(&dev));
   GPTQ_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-  if (g_cu_limit > 0) n_cu = std::max(8, std::min(n_cu, g_cu_limit));   // leave the other CUs to concurrent streams
+  if (cu_limit > 0) n_cu = std::max(8, std::min(n_cu, cu_limit));   // leave the other CUs to concurrent streams
   for (int p0 = 0; p0 < n_prob; p0 += MAX_PROB) {
     const int np = std::min(MAX_PROB, n_prob - p0);
     for (int i0 = 0; i0 < n_x; i0 += MAX_XLIST) {
@@ -1041,7 +1041,7 @@ static int hessian_launch_big(const HostProb* probs, int n_prob, int n_x, int x_
                        sizeof(float) * 2 * BTILE_FLOATS * (size_t)plan.workers);
       }
       int grid = plan.dp_tiles + plan.workers;
-      if (g_cu_limit > 0) grid = std::min(grid, n_cu);            // a real budget: the workgroups stride over the items
+      if (cu_limit > 0) grid = std::min(grid, n_cu);              // a real budget: the workgroups stride over the items
 #define HBIG(BF, RG, AB)                                                                                      \
   do {                                                                                                        \
     const size_t lds_b = (size_t)(RG) * BSTAGE;                                                               \
@@ -1050,7 +1050,9 @@ static int hessian_launch_big(const HostProb* probs, int n_prob, int n_x, int x_
     hessian16_big_kernel<BF, RG, AB><<<grid, 512, lds_b, s>>>(pg, plan, nx, tokens);                          \
   } while (0)
       static const int bring_env = [] { const char* e = getenv("GPTQ_HESS_RING"); return e ? atoi(e) : BRING_DEFAULT; }();
+#ifdef GPTQ_DIAG   // timing-only ablation builds exist in the diagnostic library alone (python -m gptq_amd.build --diag)
       static const int babl_env = [] { const char* e = getenv("GPTQ_HESS_ABLATE"); return e ? atoi(e) : 0; }();
+#endif
       if (shape16) {
         const size_t lds_b = (size_t)BRING_DEFAULT * BSTAGE;
         if (x_dtype == GPTQ_BF16) {
@@ -1066,8 +1068,10 @@ static int hessian_launch_big(const HostProb* probs, int n_prob, int n_x, int x_
         continue;
       }
       if (x_dtype == GPTQ_BF16) HBIG(true, BRING_DEFAULT, 0);
+#ifdef GPTQ_DIAG
       else if (babl_env == 1) HBIG(false, BRING_DEFAULT, 1);
       else if (babl_env == 2) HBIG(false, BRING_DEFAULT, 2);
+#endif
       else if (bring_env == 5) HBIG(false, 5, 0);
       else HBIG(false, BRING_DEFAULT, 0);
 #undef HBIG
@@ -1079,7 +1083,8 @@ static int hessian_launch_big(const HostProb* probs, int n_prob, int n_x, int x_
 }
 
 // Problems of one shape (C, ldx, ldh as in probs[0]).
-static int hessian_launch(const HostProb* probs, int n_prob, int n_x, int x_dtype, int tokens, hipStream_t s) {
+static int hessian_launch(const HostProb* probs, int n_prob, int n_x, int x_dtype, int tokens, int cu_limit,
+                          hipStream_t s) {
   const int C = probs[0].C, ldx = probs[0].ldx, ldh = probs[0].ldh;
   const int nt = cdiv(C, GBM);
   const int blocks = nt * (nt + 1) / 2;
@@ -1091,11 +1096,14 @@ static int hessian_launch(const HostProb* probs, int n_prob, int n_x, int x_dtyp
     bool big_ok = big_env != 0;
     for (int p = 0; p < n_prob; ++p) big_ok = big_ok && big_eligible(probs[p], n_x, x_dtype, tokens);
     const long big_tiles = (long)(C / BT) * (C / BT + 1) / 2 * n_prob;
-    if (big_ok && (big_env >= 2 || big_tiles >= 100)) return hessian_launch_big(probs, n_prob, n_x, x_dtype, tokens, s);
+    if (big_ok && (big_env >= 2 || big_tiles >= 100))
+      return hessian_launch_big(probs, n_prob, n_x, x_dtype, tokens, cu_limit, s);
     if (aligned) {
       static const int ring_env = [] { const char* e = getenv("GPTQ_HESS_RING"); return e ? atoi(e) : RING_DEFAULT; }();
       const size_t lds = (size_t)ring_env * DSTAGE;
+#ifdef GPTQ_DIAG
       static const int ablate = [] { const char* e = getenv("GPTQ_HESS_ABLATE"); return e ? atoi(e) : 0; }();
+#endif
       for (int p0 = 0; p0 < n_prob; p0 += MAX_PROB) {
         const int np = std::min(MAX_PROB, n_prob - p0);
         for (int i0 = 0; i0 < n_x; i0 += MAX_XLIST) {
@@ -1115,8 +1123,10 @@ static int hessian_launch(const HostProb* probs, int n_prob, int n_x, int x_dtyp
   } while (0)
           if (x_dtype == GPTQ_BF16) HDMA(true, 0, RING_DEFAULT);
           else if (ring_env == 3) HDMA(false, 0, 3);
+#ifdef GPTQ_DIAG
           else if (ablate == 1) HDMA(false, 1, RING_DEFAULT);
           else if (ablate == 2) HDMA(false, 2, RING_DEFAULT);
+#endif
           else HDMA(false, 0, RING_DEFAULT);
 #undef HDMA
         }
@@ -1175,7 +1185,7 @@ extern "C" int gptq_hessian_accum_group(int n_prob, float* const* H, int ldh, co
                         (float)(2.0 / (double)n_after),                          // gptq.py:62 squared
                         C, ldx, ldh};
   }
-  return hessian_launch(probs, n_prob, n_x, x_dtype, tokens_each, static_cast<hipStream_t>(stream));
+  return hessian_launch(probs, n_prob, n_x, x_dtype, tokens_each, 0, static_cast<hipStream_t>(stream));
 }
 
 // Problems of different widths in one call (the Linears of a block hooked in the same forward passes): those the
@@ -1183,10 +1193,11 @@ extern "C" int gptq_hessian_accum_group(int n_prob, float* const* H, int ldh, co
 // chip together and share the K-split last round -- the others go out per shape.
 extern "C" int gptq_hessian_accum_mixed(int n_prob, float* const* H, const int* ldh, const void* const* X, int n_x,
                                         int x_dtype, const int* ldx, const int* C, int tokens_each,
-                                        const int* nsamples_before, int batch_total, gptq_stream_t stream) {
+                                        const int* nsamples_before, int batch_total, int n_cu,
+                                        gptq_stream_t stream) {
   GPTQ_CHECK_ARG(n_prob > 0 && n_prob <= 64 && H && ldh && X && ldx && C && nsamples_before && n_x > 0,
                  "gptq_hessian_accum_mixed: bad arguments");
-  GPTQ_CHECK_ARG(tokens_each > 0 && batch_total > 0, "gptq_hessian_accum_mixed: bad sizes");
+  GPTQ_CHECK_ARG(tokens_each > 0 && batch_total > 0 && n_cu >= 0, "gptq_hessian_accum_mixed: bad sizes");
   hipStream_t s = static_cast<hipStream_t>(stream);
   HostProb big[64], rest[64];
   int n_big = 0, n_rest = 0;
@@ -1210,7 +1221,7 @@ extern "C" int gptq_hessian_accum_mixed(int n_prob, float* const* H, const int* 
     n_big = 0;
   }
   if (n_big > 0)
-    if (int rc = hessian_launch_big(big, n_big, n_x, x_dtype, tokens_each, s)) return rc;
+    if (int rc = hessian_launch_big(big, n_big, n_x, x_dtype, tokens_each, n_cu, s)) return rc;
   // the others: one call per shape
   bool done[64] = {};
   for (int p = 0; p < n_rest; ++p) {
@@ -1222,7 +1233,7 @@ extern "C" int gptq_hessian_accum_mixed(int n_prob, float* const* H, const int* 
         same[n++] = rest[q];
         done[q] = true;
       }
-    if (int rc = hessian_launch(same, n, n_x, x_dtype, tokens_each, s)) return rc;
+    if (int rc = hessian_launch(same, n, n_x, x_dtype, tokens_each, n_cu, s)) return rc;
   }
   return GPTQ_OK;
 }
@@ -1240,12 +1251,6 @@ extern "C" int gptq_hessian_accum(float* H, int ldh, const void* X, int x_dtype,
   GPTQ_CHECK_ARG(X != nullptr, "gptq_hessian_accum: null pointer");
   const void* xs[1] = {X};
   return gptq_hessian_accum_multi(H, ldh, xs, 1, x_dtype, ldx, C, tokens, nsamples_before, batch, stream);
-}
-
-extern "C" int gptq_hessian_cu_limit(int n_cu) {
-  GPTQ_CHECK_ARG(n_cu >= 0, "gptq_hessian_cu_limit: negative");
-  g_cu_limit = n_cu;
-  return GPTQ_OK;
 }
 
 extern "C" int gptq_symmetrize(float* A, int lda, int n, gptq_stream_t stream) {

@@ -28,11 +28,15 @@ VERBOSE = True   # the reference prints `time` / `error` per layer (gptq.py:293-
 # The fork stores `self.input = mean(scaled batch)` in add_batch (gptq.py:63); only its out-of-scope
 # `analyse` / non_linear branches read it.  It costs an extra pass over X per call, so it is opt-in.
 TRACK_INPUT_MEAN = False
-# add_batch may hold up to HESSIAN_DEFER hook inputs (references, no copies) and fold them into H with
-# ONE launch -- the reference's own multi-sample batch formula (gptq.py:44, 59-65), so only rounding
-# differs.  It divides the fp32 H read-modify-write traffic and the per-tile pipeline fill by the
-# batch.  Requires that callers do not overwrite an activation in place after its hook returned (true
-# for the OPT / LLaMA blocks); 1 = apply every call immediately, exactly like the reference.
+# HESSIAN_DEFER = 1 (default): add_batch enqueues the update of H for its input before it returns, exactly like the
+# reference (gptq.py:59-65 consumes `inp` inside the call): the launch is ordered on the current stream, so the caller
+# may overwrite or recycle the activation buffer right after the hook.
+# HESSIAN_DEFER = k > 1: add_batch holds up to k hook inputs (references, no copies) and folds them into H with ONE
+# launch -- the reference's own multi-sample batch formula (gptq.py:44, 59-65), so only rounding differs.  It divides
+# the fp32 H read-modify-write traffic and the per-tile pipeline fill by the batch.  This REQUIRES that callers do not
+# overwrite an activation in place after its hook returned (true for the OPT / LLaMA blocks: every forward produces
+# fresh tensors).  What can be checked is checked: an input whose torch version counter moved, or whose storage is
+# handed in again while still pending, raises instead of silently corrupting H.
 HESSIAN_DEFER = 1
 
 
@@ -53,10 +57,6 @@ FLUSH_EVENTS = None   # set to a list to collect ([C per problem], n_slabs, star
 # copy it when they need their own (solve, `.H`, diverging inputs).  What every object ends up with is bit for bit
 # what it would have computed alone -- the kernel, its inputs and the order of the updates are the same.
 SHARE_INPUT_HESSIANS = True
-# Put Linears of different in_features into the same Hessian launches.  Measured neutral on the OPT-1.3b block
-# (1.31 ms for fc2 + the three C = 2048 Hessians together vs 1.06 + 0.27 ms apart: the larger K-split last round
-# eats what the shared launch saves), so launches stay per width by default.
-MIX_WIDTHS = False
 # fasterquant_many solves objects that share a Hessian as one problem over the concatenation of their rows: one
 # factorization chain and one column loop for q/k/v (rows of W are independent given H, gptq.py:262-276), bit for
 # bit the per-object results.
@@ -109,18 +109,23 @@ def _plan_flush():
     return [o for o in objs if o._leader is None]
 
 
-def _launch_flush(work):
+def _launch_flush(work, n_cu=0):
     """Fold the deferred inputs of `work` (objects that own their H) into their H on the CURRENT stream, and settle the
-    bookkeeping of their followers (same inputs).  One library call per (device, slab shape, batch structure[, width]);
-    with MIX_WIDTHS the Linears of all widths go into the same call (gptq_hessian_accum_mixed then puts every width
-    the 256x256-tile kernel takes into the same launches)."""
+    bookkeeping of their followers (same inputs).  One library call per (device, slab shape, batch structure, width)
+    (Linears of different widths in one launch measured neutral: the larger K-split last round eats what the shared
+    launch saves).  n_cu > 0 sizes the launches for that many compute units (gptq_hessian_accum_mixed)."""
     import ctypes
     work = [o for o in work if o._pending and o._H is not None]
     groups = {}
     for o in work:
         x0 = o._pending[0][0]
-        key = (o.dev, x0.shape[0], x0.dtype, len(o._pending), sum(b for _, b in o._pending),
-               None if MIX_WIDTHS else o.columns)
+        for x, _, ver in o._pending:
+            if x._version != ver:
+                raise RuntimeError(
+                    "add_batch: an input tensor was modified in place after its hook returned while its Hessian update "
+                    "was still deferred (gptq_amd.gptq.HESSIAN_DEFER > 1 keeps references, not copies); set "
+                    "HESSIAN_DEFER = 1 for callers that recycle activation buffers")
+        key = (o.dev, x0.shape[0], x0.dtype, len(o._pending), sum(b for _, b, _ in o._pending), o.columns)
         groups.setdefault(key, []).append(o)
     for (dev, tokens, dtype, n_x, batch, _), members in groups.items():
         members.sort(key=lambda o: -o.columns)         # widest first: its tiles lead the launch
@@ -128,7 +133,7 @@ def _launch_flush(work):
             chunk = members[i:i + 64]
             n = len(chunk)
             Hs = (ctypes.c_void_p * n)(*[o._H.data_ptr() for o in chunk])
-            Xs = (ctypes.c_void_p * (n * n_x))(*[x.data_ptr() for o in chunk for x, _ in o._pending])
+            Xs = (ctypes.c_void_p * (n * n_x))(*[x.data_ptr() for o in chunk for x, _, _ in o._pending])
             nb = (ctypes.c_int * n)(*[int(o._applied) for o in chunk])
             ldh = (ctypes.c_int * n)(*[o._H.stride(0) for o in chunk])
             ldx = (ctypes.c_int * n)(*[o._pending[0][0].stride(0) for o in chunk])
@@ -138,13 +143,13 @@ def _launch_flush(work):
                     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     ev0.record()
                 _lib.call("gptq_hessian_accum_mixed", n, Hs, ldh, Xs, n_x, _lib._DTYPES[dtype], ldx, Cs, tokens, nb,
-                          int(batch), _lib.stream(dev))
+                          int(batch), int(n_cu), _lib.stream(dev))
                 if FLUSH_EVENTS is not None:
                     ev1.record()
                     FLUSH_EVENTS.append(([o.columns for o in chunk], n_x, ev0, ev1))
     for L in work:
         for o in [L] + list(L._followers):
-            o._applied += sum(b for _, b in o._pending)
+            o._applied += sum(b for _, b, _ in o._pending)
             o._pending = []
             o._lower_stale = True
             _DIRTY.pop(id(o), None)
@@ -232,7 +237,7 @@ def fasterquant_many(solvers, blocksize=128, percdamp=.01, groupsize=-1, actorde
             # seconds, roughly: ~200 us of latency-bound kernels per 128-column block + the GEMM flops at 100 TFLOP/s
             def cost(g):
                 own = g.members[0] if isinstance(g, _JointSolve) else g
-                hess = sum(x.shape[0] for x, _ in own._pending) * float(g.columns) ** 2 / 4e14   # deferred updates
+                hess = sum(x.shape[0] for x, _, _ in own._pending) * float(g.columns) ** 2 / 4e14   # deferred updates
                 return hess + 2e-4 * (g.columns / 128.0) + (2.0 / 3.0 * g.columns ** 3 + g.rows * g.columns ** 2) / 1e14
             order = sorted(group, key=lambda g: -cost(g))
             load = [0.0] * want                      # longest-processing-time-first onto the streams
@@ -261,13 +266,9 @@ def fasterquant_many(solvers, blocksize=128, percdamp=.01, groupsize=-1, actorde
                 st1 = lanes[1]
                 with torch.cuda.stream(st1):
                     for o in late:
-                        for x, _ in o._pending:              # inputs were allocated on the caller's stream
+                        for x, _, _ in o._pending:           # inputs were allocated on the caller's stream
                             x.record_stream(st1)
-                    _lib.call("gptq_hessian_cu_limit", int(LAZY_CUS))
-                    try:
-                        _launch_flush(late)
-                    finally:
-                        _lib.call("gptq_hessian_cu_limit", 0)
+                    _launch_flush(late, n_cu=int(LAZY_CUS))
                     late_done = torch.cuda.Event()
                     late_done.record(st1)
                 for st in lanes[2:]:
@@ -453,7 +454,8 @@ class GPTQ:
         self._H = torch.zeros((self.columns, self.columns), device=self.dev, dtype=torch.float32)
         self._lower_stale = False   # add_batch maintains the upper triangle only
         self.nsamples = 0
-        self._pending = []          # deferred (x, batch) hook inputs, see HESSIAN_DEFER
+        self._pending = []          # deferred (x, batch, x._version) hook inputs, see HESSIAN_DEFER
+        self._ptrs = {}             # their device addresses -> (base tensor, version) (aliasing guard of add_batch)
         self._applied = 0           # samples already folded into _H
         self._fresh = True          # no update folded in yet and H never assigned
         self._sig = 0               # running identity of the deferred inputs (_input_signature)
@@ -536,19 +538,41 @@ class GPTQ:
         if self._pending and (self._pending[0][0].shape != x.shape or self._pending[0][0].dtype != x.dtype
                               or self._pending[0][0].stride(0) != x.stride(0)):
             flush_pending()
-        if len(self._pending) >= max(1, int(HESSIAN_DEFER)):
+        defer = max(1, int(HESSIAN_DEFER))
+        if defer > 1 and len(self._pending) >= defer:
             # this object is about to exceed the batch: its lock-step peers (the other Linears hooked in
             # the same forward passes) hold exactly as many inputs, so everything goes out grouped by shape
-            if not LAZY_HESSIANS or int(HESSIAN_DEFER) <= 1:    # defer 1 = fold every call at once, like the reference
+            if not LAZY_HESSIANS:
                 flush_pending()
             elif 2 * self.columns >= _widest_live():          # one of the widest Linears being calibrated
                 flush_pending(heavy_only=True)
             elif len(self._pending) % 16 == 0 and _retained_bytes() > LAZY_MAX_BYTES:
                 flush_pending()
+        base = x._base if x._base is not None else x
+        if defer > 1 and self._pending and x.data_ptr() in self._ptrs:
+            # the same storage again while an update that reads it is still deferred: fine only if it is provably the
+            # same, unmodified tensor (shared version counter); a `.data` alias or a refilled staging buffer is not
+            seen_base, seen_ver = self._ptrs[x.data_ptr()]
+            if seen_base is not base or seen_ver != x._version:
+                raise RuntimeError(
+                    "add_batch: this activation buffer is still referenced by a deferred Hessian update "
+                    "(gptq_amd.gptq.HESSIAN_DEFER > 1 keeps references, not copies); set HESSIAN_DEFER = 1 for "
+                    "callers that recycle one staging buffer per sample")
         self._sig = hash((self._sig if self._pending else 0, x.data_ptr(), tuple(x.shape), tuple(x.stride()), x.dtype, batch))
-        self._pending.append((x, batch))
+        if not self._pending:
+            self._ptrs = {}
+        self._ptrs[x.data_ptr()] = (base, x._version)
+        self._pending.append((x, batch, x._version))
         _DIRTY[id(self)] = self
         self.nsamples += batch
+        if defer <= 1:
+            # like the reference: the update for `inp` is enqueued (current stream) before the hook returns, so a
+            # later in-place write to the activation is ordered behind it
+            if self._leader is not None or self._followers:
+                flush_pending()
+            else:
+                self._fresh = False
+                _launch_flush([self])
         if TRACK_INPUT_MEAN:   # fork addition (gptq.py:63), unused by the default branch
             self.input = x.mean(0, dtype=torch.float32) * math.sqrt(2 / self.nsamples)
 

@@ -110,11 +110,13 @@ def packed_shapes(u: Unit, bits: int, groupsize: int) -> Tuple[Tuple[int, int], 
 
 def allgather_packed(local: Dict[int, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]], units: Sequence[Unit],
                      assignment: Sequence[Sequence[int]], bits: int, groupsize: int,
-                     group=None) -> Dict[int, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
+                     group=None, device=None) -> Dict[int, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
     """Every rank contributes (qweight int32, scales fp32, zeros fp32) for the units it owns and
     receives everybody's.  One fixed-size all-gather: each rank's tensors are flattened into a
     single int32 buffer padded to the largest rank payload (shapes are known to all ranks from
-    `assignment`, so no size exchange is needed)."""
+    `assignment`, so no size exchange is needed).  `device`: where the exchange buffers live -- the caller's GPU;
+    it must be given when a rank may own nothing (an idle rank has no tensor to infer it from, and RCCL cannot
+    gather host tensors)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
 
@@ -127,8 +129,12 @@ def allgather_packed(local: Dict[int, Tuple[torch.Tensor, torch.Tensor, torch.Te
 
     sizes = [payload(a) for a in assignment]
     width = max(max(sizes), 1)
-    some = next(iter(local.values()))[0] if local else None
-    device = some.device if some is not None else torch.device("cpu")
+    if device is None:
+        some = next(iter(local.values()))[0] if local else None
+        if some is None and dist.get_backend(group) == "nccl":
+            raise ValueError("allgather_packed: this rank owns no unit, pass device= (RCCL needs device buffers)")
+        device = some.device if some is not None else torch.device("cpu")
+    device = torch.device(device)
     send = torch.zeros(width, dtype=torch.int32, device=device)
     off = 0
     for i in assignment[rank]:

@@ -41,7 +41,19 @@ def _run(symbol, bits, vec, mat, mul, scales, zeros, want_vec_dtype):
 
 
 def vecquant3matmul(vec, mat, mul, scales, zeros):
-    """fp32 single-token 3-bit mat-vec (quant_cuda.cpp:15-21)."""
+    """Single-token 3-bit mat-vec (quant_cuda.cpp:15-21).  fp32 operands run as they are.  The reference also
+    dispatches fp64 (AT_DISPATCH_FLOATING_TYPES, quant_cuda_kernel.cu:47): fp64 `vec/mul/scales/zeros` are accepted
+    too -- the kernel computes in fp32 (gfx950 has no fp64 matrix path worth a second kernel for a test-only dtype)
+    and the sum is added into `mul` in fp64, so the result agrees with the reference's to fp32 rounding (~1e-7
+    relative), not to fp64 rounding."""
+    if vec.dtype == torch.float64:
+        for name, t in (("mul", mul), ("scales", scales), ("zeros", zeros)):
+            if t.dtype != torch.float64:
+                raise TypeError(f"vecquant3matmul: {name} must be fp64 like vec (the reference dispatches on vec's type)")
+        acc = torch.zeros(mul.shape, dtype=torch.float32, device=mul.device)
+        _run("gptq_vecquant3matmul", 3, vec.float(), mat, acc, scales.float(), zeros.float(), torch.float32)
+        mul += acc.double()
+        return
     _run("gptq_vecquant3matmul", 3, vec, mat, mul, scales, zeros, torch.float32)
 
 

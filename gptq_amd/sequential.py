@@ -39,7 +39,7 @@ class QuantArgs:
     percdamp: float = 0.01
     groupsize: int = -1
     act_order: bool = False
-    static_groups: bool = False
+    static_groups: Optional[bool] = None   # None = the reference driver's default: True for OPT (opt.py:585), False for LLaMA (llama.py:399)
     true_sequential: bool = False
     nsamples: int = 128
     nearest: bool = False
@@ -147,10 +147,23 @@ def quantize_sequential(model, dataloader, dev, args: QuantArgs, group=None) -> 
     if world > 1 and args.wbits not in (3, 4):
         raise NotImplementedError("sharded runs exchange packed weights: wbits must be 3 or 4")
     from . import gptq as _gptq_mod
+    old_defer = _gptq_mod.HESSIAN_DEFER
+    # deferral is safe here: every hooked forward produces fresh activation tensors and nothing below writes into them
     _gptq_mod.HESSIAN_DEFER = max(1, int(args.hessian_defer))
+    try:
+        return _quantize_sequential(model, dataloader, dev, args, group, world, rank)
+    finally:
+        _gptq_mod.HESSIAN_DEFER = old_defer            # later drop-in use in this process gets the safe default back
+
+
+def _quantize_sequential(model, dataloader, dev, args, group, world, rank):
+    import torch.distributed as dist  # noqa: F401
+    from . import parallel as par
+    from .quant import dequant_packed, pack_codes
     use_cache = model.config.use_cache
     model.config.use_cache = False
     fam = _family(model)
+    static_groups = args.static_groups if args.static_groups is not None else fam["kind"] == "opt"
     layers = fam["layers"]
     inps, kwargs = _capture_layer0(model, fam, (b[0] for b in dataloader), args.nsamples, dev)
     outs = torch.zeros_like(inps)
@@ -161,6 +174,9 @@ def quantize_sequential(model, dataloader, dev, args: QuantArgs, group=None) -> 
         full = find_layers(layer)
         if args.true_sequential and fam["kind"] == "llama":
             groups = [[n for n in g if n in full] for g in LLAMA_GROUPS]
+            named = {n for g in groups for n in g}
+            rest = [n for n in full if n not in named]          # Linears the four groups do not name: quantized last,
+            groups = [g for g in groups if g] + ([rest] if rest else [])   # never silently skipped
         else:
             groups = [list(full.keys())]
         for names in groups:
@@ -195,7 +211,7 @@ def quantize_sequential(model, dataloader, dev, args: QuantArgs, group=None) -> 
             for h in handles:
                 h.remove()
             fasterquant_many(list(solvers.values()), blocksize=args.blocksize, percdamp=args.percdamp,
-                             groupsize=args.groupsize, actorder=args.act_order, static_groups=args.static_groups)
+                             groupsize=args.groupsize, actorder=args.act_order, static_groups=static_groups)
             for k in mine:
                 u = units[k]
                 key = f"{fam['prefix']}.{i}.{u.name}"
@@ -212,7 +228,8 @@ def quantize_sequential(model, dataloader, dev, args: QuantArgs, group=None) -> 
                     st, zt = _packed_tables(sv, args.groupsize)
                     local[k] = (pack_codes(sv.codes, args.wbits), st.contiguous(), zt.contiguous())
                     sv.free()
-                everything = par.allgather_packed(local, units, assignment, args.wbits, args.groupsize, group=group)
+                everything = par.allgather_packed(local, units, assignment, args.wbits, args.groupsize, group=group,
+                                                  device=dev)
                 grids = {}                                      # name -> [(row0, scale col, zero col)] of gathered slabs
                 for k, u in enumerate(units):
                     qw, st, zt = everything[k]

@@ -68,16 +68,15 @@ int gptq_hessian_accum_group(int n_prob, float* const* H, int ldh, const void* c
  * same forward passes (GPTQ.add_batch, gptq.py:38-65, once per Linear and sample in the reference).  ldh, ldx, C,
  * nsamples_before: host arrays [n_prob]; H, X as in gptq_hessian_accum_group; all problems bring n_x slabs of
  * tokens_each rows.  Problems the 256x256-tile kernel accepts (16-bit activations, C % 256 == 0, 16-byte aligned
- * rows) share its launches, so their tiles fill the chip together; the others are dispatched per shape. */
+ * rows) share its launches, so their tiles fill the chip together; the others are dispatched per shape.
+ * n_cu: work decomposition hint for THIS call -- size the launches for at most n_cu compute units (0 = the whole
+ * device): the 256x256-tile kernels then launch n_cu workgroups that stride over the whole-K tiles and the K-split
+ * runs.  For Hessian updates that run on a stream beside latency-bound work of other streams (the solves of other
+ * Linears), which needs free compute units to make progress.  Results do not depend on it beyond fp32 rounding
+ * (it moves the boundary between whole-K tiles and K-split runs). */
 int gptq_hessian_accum_mixed(int n_prob, float* const* H, const int* ldh, const void* const* X, int n_x,
                              int x_dtype, const int* ldx, const int* C, int tokens_each,
-                             const int* nsamples_before, int batch_total, gptq_stream_t stream);
-
-/* Work decomposition hint for the following gptq_hessian_accum* calls of this host thread: size the launches for at
- * most n_cu compute units (0 = the whole device): the 256x256-tile kernels then launch n_cu workgroups that stride
- * over the whole-K tiles and the K-split runs.  For Hessian updates that run on a stream beside latency-bound work
- * of other streams (the solves of other Linears), which needs free compute units to make progress. */
-int gptq_hessian_cu_limit(int n_cu);
+                             const int* nsamples_before, int batch_total, int n_cu, gptq_stream_t stream);
 
 /* Mirror the upper triangle of A [n, n] into the lower triangle. */
 int gptq_symmetrize(float* A, int lda, int n, gptq_stream_t stream);

@@ -30,3 +30,26 @@ def hip_device():
     if not torch.cuda.is_available():
         pytest.skip("no GPU visible")
     return torch.device("cuda:0")
+
+
+# ---- parity record: what the GPU tests OBSERVED (per fixture: rel-Fro, flipped codes, rows of the packed buffer that are
+# bit-identical to the reference's), written to gpurun_out/parity.json at the end of every `-m gpu` session; the copy
+# under profiles/rNN_parity.json is the tracked one.
+PARITY = {}
+
+
+def record_parity(name, **fields):
+    PARITY[name] = fields
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not PARITY:
+        return
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity.json"), "w") as f:
+            json.dump({"exitstatus": int(exitstatus), "fixtures": PARITY}, f, indent=1, sort_keys=True)
+    except OSError:
+        pass

@@ -23,7 +23,7 @@ def test_header_symbols_are_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in gptq_hip.h but not exported"
     assert sorted(_lib.EXPORTS) == names, "ctypes binding table and header disagree"
-    assert lib.gptq_hip_abi_version() == 1
+    assert lib.gptq_hip_abi_version() == 2
 
 
 def test_no_gpu_means_loud_failure_not_fallback():

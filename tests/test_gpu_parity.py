@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden_names, load_golden
+from conftest import golden_names, load_golden, record_parity
 
 pytestmark = pytest.mark.gpu
 
@@ -283,6 +283,26 @@ def _run_gptq(G, W, H, n, *, bits, sym, dtype=torch.float32, **kw):
     return lin, gp
 
 
+# Flipped integer codes allowed per reference fixture (out of R*C = 8192 ... 30720 codes).  OBSERVED on MI355X
+# (profiles/r02_parity.json): see the table there; the bound is the observed count + a margin of 2 for box-to-box
+# variation of nothing but the order of fp32 sums in the factorization chain and the trailing GEMMs.
+MAX_FLIPPED_DEFAULT = 16
+MAX_FLIPPED = {}
+
+
+def _parity_stats(G, gp, g, bits):
+    """(flipped codes, rows whose codes all match, rows whose packed int32 column is bit-identical)."""
+    ours, ref = gp.codes, cuda(g["codes"])
+    flipped = int((ours != ref).sum())
+    rows_same = int((ours == ref).all(1).sum())
+    packed_same = None
+    if bits in (3, 4) and ours.shape[1] % 32 == 0:
+        pa, pb = G.pack_codes(ours, bits), G.pack_codes(ref.contiguous(), bits)
+        packed_same = int((pa == pb).all(0).sum())
+        assert packed_same == rows_same          # packed buffer bit-exact on every row whose codes match
+    return flipped, rows_same, packed_same
+
+
 @pytest.mark.parametrize("name", [n for n in golden_names("g3_") if n != "g3_mid512"])
 def test_fasterquant_vs_reference_golden(G, name):
     g = load_golden(name)
@@ -293,22 +313,70 @@ def test_fasterquant_vs_reference_golden(G, name):
     Q = lin.weight.data.cpu()
     Qref = torch.from_numpy(g["Q"])
     # integer codes recorded from the reference run itself (oracle/gen_golden.py)
-    code_mismatch = float((gp.codes.cpu() != torch.from_numpy(g["codes"])).float().mean())
-    print(f"{name}: relFro {relfro(Q, Qref):.2e}, code mismatch {code_mismatch:.2e}, "
+    flipped, rows_same, packed_same = _parity_stats(G, gp, g, bits)
+    R, C = Qref.shape
+    rel = relfro(Q, Qref)
+    err_rel = abs(gp.error - float(g["error"])) / abs(float(g["error"]))
+    record_parity(name, shape=[R, C], bits=bits, relfro_Q=rel, flipped_codes=flipped, codes=R * C, rows=R,
+                  rows_codes_identical=rows_same, rows_packed_bit_identical=packed_same, error_rel=err_rel,
+                  weights_bit_identical=bool(torch.equal(Q, Qref)))
+    print(f"{name}: relFro {rel:.2e}, flipped codes {flipped}/{R * C}, rows identical {rows_same}/{R}, "
           f"error {gp.error:.6g} vs {float(g['error']):.6g}")
-    assert relfro(Q, Qref) <= 1e-3
-    assert code_mismatch <= 2e-3
-    assert abs(gp.error - float(g["error"])) <= 1e-3 * abs(float(g["error"]))
+    assert rel <= 1e-3
+    assert flipped <= MAX_FLIPPED.get(name, MAX_FLIPPED_DEFAULT)
+    assert err_rel <= 1e-3
     # The grid left in the quantizer is order-independent arithmetic on its inputs: exact when it comes
     # from the original weights (no groups / static groups).  Dynamic groups read compensated weights,
     # whose last bits depend on the trailing GEMM's summation order, so the grid may move by an ulp.
     sref, zref = torch.from_numpy(g["scale"]), torch.from_numpy(g["zero"])
     if int(g["groupsize"]) == -1 or bool(g["static_groups"]):
         assert torch.equal(gp.quantizer.scale.cpu(), sref) and torch.equal(gp.quantizer.zero.cpu(), zref)
-        assert float((Q != Qref).float().mean()) <= 2e-3
+        # every element whose code matches is the same fp32 number: Q = scale * (code - zero), same grid
+        assert int((Q != Qref).sum()) <= flipped
     else:
         assert relfro(gp.quantizer.scale.cpu(), sref) <= 1e-5
     assert int(gp.codes.max()) <= 2 ** bits - 1
+
+
+# Mid-size reference runs with the flag sets the BASELINE configs use (oracle/gen_golden_mid.py): the real calling
+# sequence -- fp16 Linear, add_batch from the stored fp16 calibration samples, fasterquant -- against the reference's
+# codes and grids.  Flipped-code bound per fixture: observed count (profiles/r02_parity.json) + margin.
+MID_MAX_FLIPPED = {"g5_mid1024_g128_static": 64, "g5_mid1024_actorder": 64, "g5_mid1024_3bit": 64}
+
+
+@pytest.mark.parametrize("name", ["g5_mid1024_g128_static", "g5_mid1024_actorder", "g5_mid1024_3bit"])
+def test_fasterquant_mid1024_reference_flag_sets(G, name):
+    inp = load_golden("g5_mid1024_inputs")
+    g = load_golden(name)
+    bits = int(g["bits"])
+    lin = make_linear(cuda(inp["W"]).float())           # fp32 Linear holding fp16-representable weights, as generated
+    gp = G.GPTQ(lin)
+    gp.quantizer = G.Quantizer(); gp.quantizer.configure(bits, perchannel=True, sym=False, mse=False)
+    for k in range(inp["X"].shape[0]):
+        gp.add_batch(cuda(inp["X"][k]), None)
+    gp.fasterquant(blocksize=128, percdamp=0.01, groupsize=int(g["groupsize"]), actorder=bool(g["actorder"]),
+                   static_groups=bool(g["static_groups"]))
+    flipped, rows_same, packed_same = _parity_stats(G, gp, g, bits)
+    R, C = gp.codes.shape
+    err_rel = abs(gp.error - float(g["error"])) / abs(float(g["error"]))
+    # dequantized reference weights from its codes and grids (exactly its Q, asserted by the generator)
+    if int(g["groupsize"]) > 0:
+        grp = torch.arange(C) // int(g["groupsize"])
+        cs, cz = torch.from_numpy(g["group_scale"])[:, grp], torch.from_numpy(g["group_zero"])[:, grp]
+        assert torch.equal(gp.group_scale.cpu(), torch.from_numpy(g["group_scale"]))      # static groups: exact grids
+        assert torch.equal(gp.group_zero.cpu(), torch.from_numpy(g["group_zero"]))
+    else:
+        cs, cz = torch.from_numpy(g["scale"]), torch.from_numpy(g["zero"])
+        assert torch.equal(gp.quantizer.scale.cpu(), cs) and torch.equal(gp.quantizer.zero.cpu(), cz)
+    Qref = cs * (torch.from_numpy(g["codes"]).float() - cz)
+    rel = relfro(lin.weight.data.cpu(), Qref)
+    record_parity(name, shape=[R, C], bits=bits, relfro_Q=rel, flipped_codes=flipped, codes=R * C, rows=R,
+                  rows_codes_identical=rows_same, rows_packed_bit_identical=packed_same, error_rel=err_rel,
+                  hessian="accumulated on the GPU from the stored fp16 samples")
+    print(f"{name}: relFro {rel:.2e}, flipped codes {flipped}/{R * C} ({flipped / (R * C):.1e}), rows identical "
+          f"{rows_same}/{R}, error rel {err_rel:.1e}")
+    assert rel <= 1e-3 and err_rel <= 1e-3
+    assert flipped <= MID_MAX_FLIPPED[name]
 
 
 def test_fasterquant_mid512_codes(G):
@@ -414,7 +482,7 @@ def test_shared_input_hessians_match_private_ones(G, defer):
                 objs[2].add_batch(xs[k] if k < 3 else other, None)      # diverges at the 4th sample
                 objs[3].add_batch(other, None)                            # never shares
             gm.flush_pending()
-            if share:
+            if share and defer > 1:          # defer 1 launches inside add_batch like the reference: nothing to share
                 assert objs[1]._leader is objs[0] and objs[2]._leader is None and objs[3]._leader is None
             Hs = [o.H.clone() for o in objs]
             objs[1].fasterquant(blocksize=128, percdamp=0.01, groupsize=128)   # a follower first, then its leader
@@ -661,6 +729,168 @@ def test_full_size_pack_matvec_roundtrip(G, O, hip_device):
     assert np.array_equal(back, codes[:, :1024].t().cpu().numpy().astype(np.uint32))
 
 
+def _full_size_checks(G, W, lin, gp, H, bits, actorder, n_rtn_note=""):
+    """Size-independent properties of one finished solve at a BASELINE shape (per-row grid, groupsize -1)."""
+    dev = W.device
+    R, C = W.shape
+    codes = gp.codes
+    assert int(codes.max()) <= 2 ** bits - 1
+    s, z = gp.quantizer.scale, gp.quantizer.zero                     # [R, 1]
+    # on-grid: the fp32 Q is exactly scale * (code - zero) (then cast to fp16, gptq.py:305)
+    assert torch.equal(lin.weight.data, (s * (codes.float() - z)).half())
+    # the grid is find_params of the (dead-zeroed, here untouched) original weights: order-independent, exact
+    q = G.Quantizer(); q.configure(bits, perchannel=True, sym=False, mse=False)
+    q.find_params(W.float(), weight=True)
+    assert torch.equal(q.scale, s) and torch.equal(q.zero, z)
+    Hd = H.double()
+    if actorder:
+        perm = gp.perm.long()
+        assert torch.equal(torch.sort(perm)[0], torch.arange(C, device=dev))          # a permutation
+        d = torch.diag(H)[perm]
+        assert bool((d[:-1] >= d[1:]).all())                                            # descending diag (gptq.py:166)
+        Hd = Hd[perm][:, perm]
+    # U^T U (H + damp I) = I in fp64
+    U = gp.Hinv.double()
+    assert torch.equal(gp.Hinv, torch.triu(gp.Hinv))
+    Hd = Hd + torch.eye(C, device=dev, dtype=torch.float64) * 0.01 * torch.diag(H.double()).mean()
+    resid = (U.t() @ (U @ Hd) - torch.eye(C, device=dev, dtype=torch.float64)).norm() / math.sqrt(C)
+    del U, Hd
+    # GPTQ beats round-to-nearest on the layer-output proxy tr((W-Q) H (W-Q)^T)
+    Wf = W.float()
+    rtn = G.quantize(Wf, s, z, q.maxq)
+
+    def proxy(Q):
+        D = (Wf - Q.float()).double()
+        return float(((D @ H.double()) * D).sum())
+    p_gptq, p_rtn = proxy(lin.weight.data), proxy(rtn)
+    return float(resid), p_gptq, p_rtn
+
+
+def _calibrated(G, W, n_samples, seed, bits):
+    dev = W.device
+    R, C = W.shape
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    lin = make_linear(W)
+    gp = G.GPTQ(lin)
+    gp.quantizer = G.Quantizer(); gp.quantizer.configure(bits, perchannel=True, sym=False, mse=False)
+    chan = (1 + torch.arange(C, device=dev) % 7).half()
+    for _ in range(n_samples):
+        gp.add_batch(torch.randn(1, 2048, C, device=dev, generator=gen).half() * chan, None)
+    return lin, gp
+
+
+@pytest.mark.parametrize("R,C", [(4096, 4096), (4096, 11008)])
+def test_full_size_properties_llama7b_actorder(G, hip_device, R, C):
+    """BASELINE configs[2]: Llama-7B q/k/v/o (4096 x 4096) and down_proj (4096 x 11008: 43 tiles of 256, 86 blocks of
+    128), 4-bit, per-row grid, --act-order."""
+    G.gptq.VERBOSE = False
+    gen = torch.Generator(device="cuda").manual_seed(C)
+    W = (torch.randn(R, C, device=hip_device, generator=gen) * 0.02).half()
+    lin, gp = _calibrated(G, W, 6, 100 + C, 4)
+    H = gp.H.clone()
+    assert torch.equal(H, H.t())
+    gp.fasterquant(blocksize=128, percdamp=0.01, groupsize=-1, actorder=True)
+    resid, p_gptq, p_rtn = _full_size_checks(G, W, lin, gp, H, 4, True)
+    record_parity(f"full_llama7b_{R}x{C}_actorder", resid_UtU_H=resid, proxy_gptq=p_gptq, proxy_rtn=p_rtn, error=gp.error)
+    print(f"llama7b {R}x{C} act-order: |U^T U (H+dI) - I|/sqrt(C) = {resid:.2e}, proxy gptq/rtn = {p_gptq / p_rtn:.3f}")
+    assert resid <= 1e-4
+    assert p_gptq < 0.95 * p_rtn
+
+
+def test_full_size_llama7b_joint_gate_up_equals_separate(G, hip_device):
+    """gate_proj / up_proj (11008 x 4096 each) are fed one tensor: fasterquant_many solves them as ONE problem over
+    22016 stacked rows (one chain, one column loop); results must be bit for bit those of two separate solves."""
+    gm = G.gptq
+    gm.VERBOSE = False
+    old = (gm.HESSIAN_DEFER, gm.JOINT_SOLVE)
+    gm.HESSIAN_DEFER = 4
+    try:
+        res = {}
+        for joint in (False, True):
+            gm.JOINT_SOLVE = joint
+            gen = torch.Generator(device="cuda").manual_seed(9)
+            Ws = [(torch.randn(11008, 4096, device=hip_device, generator=gen) * 0.02).half() for _ in range(2)]
+            objs = []
+            for W in Ws:
+                gp = G.GPTQ(make_linear(W))
+                gp.quantizer = G.Quantizer(); gp.quantizer.configure(4, perchannel=True, sym=False, mse=False)
+                objs.append(gp)
+            chan = (1 + torch.arange(4096, device=hip_device) % 7).half()
+            for _ in range(4):
+                x = torch.randn(1, 2048, 4096, device=hip_device, generator=gen).half() * chan
+                for gp in objs:
+                    gp.add_batch(x, None)
+            G.fasterquant_many(objs, blocksize=128, percdamp=0.01, groupsize=-1, actorder=True)
+            res[joint] = [(o.codes.clone(), o.layer.weight.data.clone(), o.perm.clone(), o.error) for o in objs]
+            for o in objs:
+                o.free()
+        for a, b in zip(res[False], res[True]):
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+            assert abs(a[3] - b[3]) <= 1e-5 * abs(a[3])
+    finally:
+        gm.HESSIAN_DEFER, gm.JOINT_SOLVE = old
+
+
+def test_full_size_properties_opt6p7b_fc2_3bit(G, hip_device):
+    """BASELINE configs[3]: OPT-6.7b fc2 (4096 x 16384: 64 tiles of 256, 128 blocks of 128), 3-bit, per-row grid."""
+    G.gptq.VERBOSE = False
+    R, C = 4096, 16384
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    W = (torch.randn(R, C, device=hip_device, generator=gen) * 0.02).half()
+    lin, gp = _calibrated(G, W, 10, 77, 3)
+    H = gp.H.clone()
+    gp.fasterquant(blocksize=128, percdamp=0.01, groupsize=-1, static_groups=True)   # opt.py:585 (no-op without groups)
+    resid, p_gptq, p_rtn = _full_size_checks(G, W, lin, gp, H, 3, False)
+    record_parity("full_opt6.7b_fc2_4096x16384_3bit", resid_UtU_H=resid, proxy_gptq=p_gptq, proxy_rtn=p_rtn, error=gp.error)
+    print(f"opt6.7b fc2 3-bit: |U^T U (H+dI) - I|/sqrt(C) = {resid:.2e}, proxy gptq/rtn = {p_gptq / p_rtn:.3f}")
+    assert resid <= 1e-4
+    assert p_gptq < 0.95 * p_rtn
+    # the packed 3-bit buffer of these codes decodes back to them (first 1024 input columns on the host)
+    qw = G.pack_codes(gp.codes, 3)
+    assert qw.shape == (C // 32 * 3, R)
+    from oracle import gptq_oracle as O
+    back = O.unpack3(qw[:96].cpu().numpy())
+    assert np.array_equal(back, gp.codes[:, :1024].t().cpu().numpy().astype(np.uint32))
+
+
+@pytest.mark.parametrize("bits", [3, 4])
+def test_full_size_matvec_fc2_36864_to_9216(G, hip_device, bits):
+    """The kernel-benchmark shape BASELINE configs[3] names (FC2 of OPT-66B dims: in = 36864, out = 9216; README.md:92):
+    packed mat-vec against a dense fp64 product of the dequantized weights on the GPU."""
+    in_f, out_f = 36864, 9216
+    gen = torch.Generator(device="cuda").manual_seed(bits)
+    codes = torch.randint(0, 2 ** bits, (out_f, in_f), device=hip_device, generator=gen, dtype=torch.uint8)
+    qw = G.pack_codes(codes, bits)
+    assert qw.shape == (in_f // 32 * bits, out_f)
+    scales = torch.rand(out_f, 1, device=hip_device, generator=gen) * 0.01 + 1e-3
+    zeros = torch.randint(0, 2 ** bits, (out_f, 1), device=hip_device, generator=gen).float() * scales
+    bias = torch.randn(out_f, device=hip_device, generator=gen)
+    x = torch.randn(in_f, device=hip_device, generator=gen)
+    from gptq_amd import quant_cuda
+    fn = quant_cuda.vecquant3matmul if bits == 3 else quant_cuda.vecquant4matmul
+    fn16 = quant_cuda.vecquant3matmul_faster if bits == 3 else quant_cuda.vecquant4matmul
+    Wd = scales.double() * codes.double() - zeros.double()                      # [out, in] fp64, quant_cuda_kernel.cu:118
+    ref = bias.double() + Wd @ x.double()
+    y = bias.clone()
+    fn(x, qw, y, scales, zeros)
+    err32 = float((y.double() - ref).abs().max() / ref.abs().max())
+    x16 = x.half()
+    ref16 = bias.double() + Wd @ x16.double()
+    y16 = bias.clone()
+    fn16(x16, qw, y16, scales, zeros)
+    err16 = float((y16.double() - ref16).abs().max() / ref16.abs().max())
+    record_parity(f"full_matvec_36864x9216_{bits}bit", max_rel_fp32_x=err32, max_rel_fp16_x=err16)
+    print(f"matvec 36864->9216 {bits}-bit: max rel err fp32 x {err32:.1e}, fp16 x {err16:.1e}")
+    assert err32 <= 1e-5 and err16 <= 1e-2
+    # linearity (size-independent property)
+    x2 = torch.randn(in_f, device=hip_device, generator=gen)
+    def mv(v):
+        o = torch.zeros(out_f, device=hip_device)
+        fn(v, qw, o, scales, zeros)
+        return o
+    assert relfro(mv(x + 2 * x2).cpu(), (mv(x) + 2 * mv(x2)).cpu()) <= 1e-5
+
+
 # ------------------------------------------- f16/bf16 MFMA Hessian: exact products, fp32 accumulate
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_hessian_16bit_mfma_precision_full_sequence(G, O, hip_device, dtype):
@@ -858,30 +1088,109 @@ def test_lazy_hessians_fold_narrow_linears_beside_the_solve(G):
         gm.FLUSH_EVENTS = None
 
 
-def test_hessians_of_different_widths_in_one_flush(G):
-    """Linears of different in_features hooked in the same forward passes go out in one library call
-    (gptq_hessian_accum_mixed): every H must match fp64, whichever kernel its width selects."""
+def test_hessians_of_different_widths_in_one_call(G):
+    """Linears of different in_features in one library call (gptq_hessian_accum_mixed, also with a CU budget):
+    every H must match fp64, whichever kernel its width selects."""
+    import ctypes
+    from gptq_amd import _lib
+    g2 = torch.Generator().manual_seed(11)
+    widths = [1024, 512, 320, 768, 512]                  # 320: not a multiple of 256 (128x128 / ragged kernels)
+    n_x = 5
+    for n_cu in (0, 24):
+        xs = [[(torch.randn(96, C, generator=g2) * (1 + torch.arange(C) % 5)).half().cuda() for _ in range(n_x)]
+              for C in widths]
+        Hs = [torch.zeros(C, C, device="cuda") for C in widths]
+        n = len(widths)
+        _lib.call("gptq_hessian_accum_mixed", n, (ctypes.c_void_p * n)(*[h.data_ptr() for h in Hs]),
+                  (ctypes.c_int * n)(*widths), (ctypes.c_void_p * (n * n_x))(*[x.data_ptr() for x5 in xs for x in x5]),
+                  n_x, _lib.F16, (ctypes.c_int * n)(*widths), (ctypes.c_int * n)(*widths), 96,
+                  (ctypes.c_int * n)(*([0] * n)), n_x, n_cu, _lib.stream(Hs[0].device))
+        for H, x5 in zip(Hs, xs):
+            X = torch.cat(x5, 0).double()
+            ref = (2.0 / n_x) * (X.t() @ X)
+            up = torch.triu(torch.ones_like(ref, dtype=torch.bool))
+            assert float((H.double() - ref)[up].norm() / ref[up].norm()) < 2e-6
+
+
+def test_add_batch_consumes_its_input_inside_the_call(G, O, hip_device):
+    """HESSIAN_DEFER = 1 (default): like gptq.py:59-65 the update for `inp` is enqueued before add_batch returns, so a
+    caller may refill ONE staging buffer per sample.  With deferral the same pattern is refused loudly."""
     gm = G.gptq
-    old = (gm.HESSIAN_DEFER, gm.SHARE_INPUT_HESSIANS, gm.MIX_WIDTHS)
-    gm.HESSIAN_DEFER, gm.MIX_WIDTHS = 3, True
+    assert gm.HESSIAN_DEFER == 1
+    gen = torch.Generator().manual_seed(3)
+    C, S = 256, 128
+    xs = [(torch.randn(1, S, C, generator=gen) * (1 + torch.arange(C) % 7)).half() for _ in range(5)]
+    Href = torch.zeros(C, C)
+    n = 0
+    for x in xs:
+        n = O.hessian_add_batch(Href, n, x)
+    gp = G.GPTQ(make_linear(torch.zeros(4, C, device=hip_device)))
+    buf = torch.empty(1, S, C, device=hip_device, dtype=torch.float16)
+    for x in xs:
+        buf.copy_(x)                      # the previous sample is overwritten right after its hook returned
+        gp.add_batch(buf, None)
+        assert not gp._pending
+    assert relfro(gp.H.cpu(), Href) <= 1e-6
+    old = gm.HESSIAN_DEFER
     try:
-        g2 = torch.Generator().manual_seed(11)
-        widths = [1024, 512, 320, 768, 512]                  # 320: not a multiple of 256 (128x128 / ragged kernels)
-        objs, xs = [], []
-        for C in widths:
-            gp = G.GPTQ(make_linear((torch.randn(8, C, generator=g2) * 0.02).half().cuda()))
-            objs.append(gp)
-            xs.append([(torch.randn(1, 96, C, generator=g2) * (1 + torch.arange(C) % 5)).half().cuda() for _ in range(5)])
-        for k in range(5):
-            for gp, x in zip(objs, xs):
-                gp.add_batch(x[k], None)
-        for gp, x in zip(objs, xs):
-            X = torch.cat([t[0] for t in x], 0).double()
-            ref = (2.0 / 5.0) * (X.t() @ X)
-            assert relfro(gp.H.double().cpu(), ref.cpu()) < 2e-6
-            assert torch.equal(gp.H, gp.H.t())
+        gm.HESSIAN_DEFER = 4
+        gp = G.GPTQ(make_linear(torch.zeros(4, C, device=hip_device)))
+        buf.copy_(xs[0]); gp.add_batch(buf, None)
+        buf.copy_(xs[1])
+        with pytest.raises(RuntimeError, match="HESSIAN_DEFER"):
+            gp.add_batch(buf, None)       # same storage, version moved
+        gp = G.GPTQ(make_linear(torch.zeros(4, C, device=hip_device)))
+        gp.add_batch(buf.data, None)
+        with pytest.raises(RuntimeError, match="HESSIAN_DEFER"):
+            gp.add_batch(buf.data, None)  # a `.data` alias: no shared version counter, refused
+        gp = G.GPTQ(make_linear(torch.zeros(4, C, device=hip_device)))
+        y = xs[2].cuda()
+        gp.add_batch(y, None)
+        y.mul_(2)                          # modified after the hook, before the deferred launch
+        with pytest.raises(RuntimeError, match="HESSIAN_DEFER"):
+            gm.flush_pending()
+        gp.free()
     finally:
-        gm.HESSIAN_DEFER, gm.SHARE_INPUT_HESSIANS, gm.MIX_WIDTHS = old
+        gm.HESSIAN_DEFER = old
+        for o in list(gm._DIRTY.values()):
+            o.free()
+
+
+def test_quantize_per_column_grid_on_square_input_broadcasts_like_torch(G, hip_device):
+    """quant.py:9-10 is plain broadcasting: a [1, C] (or [C]) grid applies along columns even when R == C."""
+    gen = torch.Generator().manual_seed(4)
+    x = torch.randn(64, 64, generator=gen)
+    scale = torch.rand(1, 64, generator=gen) * 0.1 + 0.01
+    zero = torch.randint(0, 16, (1, 64), generator=gen).float()
+    ref = scale * (torch.clamp(torch.round(x / scale) + zero, 0, 15) - zero)
+    for s, z in ((scale, zero), (scale.reshape(-1), zero.reshape(-1))):
+        got = G.quantize(x.to(hip_device), s.to(hip_device), z.to(hip_device), torch.tensor(15))
+        assert torch.equal(got.cpu(), ref)
+    col = scale.reshape(-1, 1)
+    got = G.quantize(x.to(hip_device), col.to(hip_device), zero.reshape(-1, 1).to(hip_device), torch.tensor(15))
+    assert torch.equal(got.cpu(), col * (torch.clamp(torch.round(x / col) + zero.reshape(-1, 1), 0, 15) - zero.reshape(-1, 1)))
+
+
+def test_vecquant3matmul_fp64_operands(G, O):
+    """The reference dispatches fp32 AND fp64 (quant_cuda_kernel.cu:47); fp64 operands are accepted, computed in
+    fp32 and accumulated into the fp64 `mul` (agreement to fp32 rounding)."""
+    rng = np.random.default_rng(5)
+    in_f, out_f = 512, 384
+    iw = rng.integers(0, 8, size=(in_f, out_f), dtype=np.uint32)
+    qw = O.pack3(iw)
+    scales = (rng.random(out_f) * 0.02 + 0.001)
+    zeros = rng.integers(0, 8, size=out_f) * scales
+    bias = rng.standard_normal(out_f)
+    x = rng.standard_normal(in_f)
+    ref = bias + x @ (iw.astype(np.float64) * scales - zeros)
+    from gptq_amd import quant_cuda
+    y = cuda(bias.copy())
+    assert y.dtype == torch.float64
+    quant_cuda.vecquant3matmul(cuda(x), cuda(qw), y, cuda(scales).reshape(-1, 1), cuda(zeros).reshape(-1, 1))
+    assert np.abs(y.cpu().numpy() - ref).max() <= 1e-5 * np.abs(ref).max()
+    with pytest.raises(TypeError):
+        quant_cuda.vecquant3matmul(cuda(x), cuda(qw), cuda(bias.astype(np.float32)), cuda(scales).reshape(-1, 1),
+                                   cuda(zeros).reshape(-1, 1))
 
 
 # ----------------------------------------------------------------- kernel variants selected by environment

@@ -11,8 +11,13 @@ dev = torch.device("cuda:0")
 lib = _lib.load()
 
 
+CU_LIMIT = int(os.environ.get("GPTQ_CHECK_CU_LIMIT", "0"))   # size every launch for that many compute units
+
+
 def accum(Hs, Xs, nb, batch):
     """Hs: list of [C,C] fp32; Xs: list (per problem) of lists of [tokens, C] slabs."""
+    if CU_LIMIT:                       # the CU budget is an argument of the mixed-width entry point
+        return accum_mixed(Hs, Xs, nb, batch)
     n_x = len(Xs[0])
     C = Hs[0].shape[0]
     Hp = (ctypes.c_void_p * len(Hs))(*[h.data_ptr() for h in Hs])
@@ -58,7 +63,7 @@ def accum_mixed(Hs, Xs, nb, batch):
     Cs = (ctypes.c_int * n)(*[h.shape[0] for h in Hs])
     x0 = Xs[0][0]
     _lib.call("gptq_hessian_accum_mixed", n, Hp, ldh, Xp, n_x, _lib._DTYPES[x0.dtype], ldx, Cs, x0.shape[0], nbp, batch,
-              _lib.stream(dev))
+              CU_LIMIT, _lib.stream(dev))
 
 
 def check_mixed(widths, tokens, n_x, dtype):
@@ -115,8 +120,6 @@ def timeit(C, n_prob, n_x=8, tokens=2048, reps=5):
 
 
 args = sys.argv[1:]
-if os.environ.get("GPTQ_CHECK_CU_LIMIT"):            # size every launch for that many compute units
-    _lib.call("gptq_hessian_cu_limit", int(os.environ["GPTQ_CHECK_CU_LIMIT"]))
 print("GPTQ_HESS_BIG =", os.environ.get("GPTQ_HESS_BIG", "(default)"), "RING =", os.environ.get("GPTQ_HESS_RING", "-"),
       "ABLATE =", os.environ.get("GPTQ_HESS_ABLATE", "-"), flush=True)
 if "--time-only" in args:          # --time-only C:problems [C:problems ...]
