@@ -391,7 +391,7 @@ class _JointSolve:
         q0 = members[0].quantizer
         for m in members:
             q = m.quantizer
-            if not isinstance(m.layer, nn.Linear) and type(m.layer).__name__ != "_RowSlab":
+            if not isinstance(m.layer, nn.Linear):
                 return False
             if int(q.maxq) != int(q0.maxq) or bool(q.sym) != bool(q0.sym) or int(q.maxq) < 0:
                 return False

@@ -1,80 +1,23 @@
-"""Module-level sharding of one transformer block's Linears across the GPUs of a node.
+"""Sharding one transformer block's GPTQ work across the GPUs of a node.
 
 The reference has no distributed code; this is the capability BASELINE
-config 5 / north_star adds: the Linears hooked in one forward pass are independent GPTQ
-problems (opt.py:189-214 walks them serially only for convenience), so they are dealt to
-ranks by cost and the only exchange is an all-gather of the PACKED weights (+ grids) at the
-block boundary -- every rank needs them to run the post-quantization forward (opt.py:216-217).
-One process per GPU, torch.distributed ("nccl" = RCCL over xGMI on ROCm; "gloo" on CPU in tests).
+config 5 / north_star adds.  One process per GPU, torch.distributed ("nccl" = RCCL over xGMI on
+ROCm; "gloo" on CPU in tests).  Two layers:
+
+  * `fasterquant_sharded` -- the data-parallel path: every rank folds ITS share of the
+    calibration samples into the Hessians (add_batch), one all-reduce of H per distinct Hessian, the
+    factorization chain replicated on the ranks that need it, the ROWS of W split over the ranks (rows are
+    independent problems given H, gptq.py:262-276), one all-gather of the packed rows + grids.  Every rank ends
+    up with bit-identical quantized weights for the post-quantization forward (opt.py:216-217).
+  * `assign_units` -- longest-processing-time-first dealing of whole problems to ranks (used when there are more
+    distinct Hessians than ranks: Linears hooked in one forward pass are independent problems, opt.py:189-214).
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
-from typing import Dict, List, Sequence, Tuple
+from typing import List, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
-
-
-@dataclass(frozen=True)
-class Unit:
-    """One Linear to quantize -- or a ROW SLAB of one: `name`, rows R (of the slab), in_features C, and the slab's
-    first row in the Linear (`row0`; `full_rows` = the Linear's out_features, 0 when the unit is the whole Linear).
-    Rows of W are independent problems given H (per-row grids, per-row error feedback, gptq.py:262-276), so a slab
-    is solved exactly like a Linear with fewer outputs; its owner needs the full Hessian."""
-    name: str
-    rows: int
-    cols: int
-    row0: int = 0
-    full_rows: int = 0
-
-    @property
-    def params(self) -> int:
-        return self.rows * self.cols
-
-
-def unit_cost(u: Unit, nsamples: int, seqlen: int, blocksize: int = 128) -> float:
-    """fp32 flop model of the path for one Linear: Hessian SYRK (upper half)
-    + factorization chain (2/3 C^3 here) + trailing updates (R C^2) + in-block rank-1 updates."""
-    R, C = u.rows, u.cols
-    return nsamples * seqlen * C * C + (2.0 / 3.0) * C ** 3 + R * C * C + R * C * blocksize
-
-
-def split_rows(u: Unit, k: int, align: int = 128) -> List[Unit]:
-    """`u` as k row slabs of (nearly) equal height, boundaries on multiples of `align` (fewer slabs if R is small)."""
-    blocks = max(1, -(-u.rows // align))
-    k = max(1, min(k, blocks))
-    out, start = [], 0
-    for j in range(k):
-        nb = blocks // k + (1 if j < blocks % k else 0)
-        stop = min(u.rows, start + nb * align)
-        out.append(Unit(u.name, stop - start, u.cols, u.row0 + start, u.full_rows or u.rows))
-        start = stop
-    return out
-
-
-def plan_units(shapes: Sequence[Tuple[str, int, int]], world: int, nsamples: int, seqlen: int, blocksize: int = 128,
-               row_slabs: int = 1) -> Tuple[List[Unit], List[float], List[List[int]]]:
-    """Units (Linears or row slabs), their costs and the per-rank assignment for the Linears `shapes` = (name, R, C)
-    hooked in one forward pass.  row_slabs: 0 = whole Linears only; 1 = split the costliest Linear into as many slabs
-    as ranks would otherwise idle (fewer Linears than ranks: LLaMA's true-sequential [o] and [down] groups);
-    k >= 2 = split every Linear into k slabs.  A slab owner accumulates the full Hessian and runs the full
-    factorization chain (they depend on H only), so slabs shard only the row-proportional work: the trailing
-    updates R*C^2 and the column loop."""
-    units = [Unit(n, r, c) for (n, r, c) in shapes]
-    cost = lambda u: unit_cost(u, nsamples, seqlen, blocksize)
-    if row_slabs >= 2:
-        units = [s for u in units for s in split_rows(u, row_slabs)]
-    elif row_slabs == 1 and world > len(units):
-        big = max(range(len(units)), key=lambda i: (cost(units[i]), -i))
-        units = units[:big] + split_rows(units[big], world - len(units) + 1) + units[big + 1:]
-    costs = [cost(u) for u in units]
-    return units, costs, assign_units(costs, world)
-
-
-def hessian_cost(u: Unit, nsamples: int, seqlen: int) -> float:
-    """The Hessian term of `unit_cost` (Linears fed the same input share it, gptq.SHARE_INPUT_HESSIANS)."""
-    return float(nsamples) * seqlen * u.cols * u.cols
 
 
 def assign_units(costs: Sequence[float], world: int, bundles: Sequence[Sequence[int]] = (),
@@ -102,61 +45,280 @@ def assign_units(costs: Sequence[float], world: int, bundles: Sequence[Sequence[
     return [sorted(a) for a in out]
 
 
-def packed_shapes(u: Unit, bits: int, groupsize: int) -> Tuple[Tuple[int, int], Tuple[int, int]]:
-    """(qweight shape, grid-table shape) of a packed Linear."""
-    groups = 1 if groupsize <= 0 else -(-u.cols // groupsize)
-    return (u.cols // 32 * bits, u.rows), (u.rows, groups)
+# ------------------------------------------------------------------------------------------------
+# Data-parallel solve: all-reduce of H, row-sharded column loop, all-gather of the packed rows
+# ------------------------------------------------------------------------------------------------
+def tri_blocks(C: int, bs: int = 256) -> List[Tuple[int, int, int]]:
+    """(r0, r1, offset) of the row blocks of the upper trapezoid layout: rows [r0, r1) x columns [r0, C), packed one
+    after the other.  add_batch maintains only the upper triangle of H, so this is all an exchange has to carry:
+    C^2/2 + bs*C/2 elements instead of C^2."""
+    out, off = [], 0
+    for r0 in range(0, C, bs):
+        r1 = min(C, r0 + bs)
+        out.append((r0, r1, off))
+        off += (r1 - r0) * (C - r0)
+    return out
 
 
-def allgather_packed(local: Dict[int, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]], units: Sequence[Unit],
-                     assignment: Sequence[Sequence[int]], bits: int, groupsize: int,
-                     group=None, device=None) -> Dict[int, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
-    """Every rank contributes (qweight int32, scales fp32, zeros fp32) for the units it owns and
-    receives everybody's.  One fixed-size all-gather: each rank's tensors are flattened into a
-    single int32 buffer padded to the largest rank payload (shapes are known to all ranks from
-    `assignment`, so no size exchange is needed).  `device`: where the exchange buffers live -- the caller's GPU;
-    it must be given when a rank may own nothing (an idle rank has no tensor to infer it from, and RCCL cannot
-    gather host tensors)."""
+def tri_numel(C: int, bs: int = 256) -> int:
+    r0, r1, off = tri_blocks(C, bs)[-1]
+    return off + (r1 - r0) * (C - r0)
+
+
+def allreduce_hessian(H: torch.Tensor, n_local: int, group=None) -> int:
+    """H <- sum_r (n_r / n) H_r over the ranks (in place, upper triangle only), n = sum_r n_r; returns n.
+    H_r is the reference's running mean over the n_r samples rank r folded in (gptq.py:59-65): the weighted sum is
+    the running mean over all n samples up to fp32 rounding.  One collective: the trapezoid-packed upper triangle,
+    pre-scaled by n_r, with n_r itself in the last element."""
+    C = H.shape[0]
+    blocks = tri_blocks(C)
+    numel = tri_numel(C)
+    flat = torch.empty(numel + 1, device=H.device, dtype=torch.float32)
+    for r0, r1, off in blocks:
+        torch.mul(H[r0:r1, r0:], float(n_local), out=flat[off:off + (r1 - r0) * (C - r0)].view(r1 - r0, C - r0))
+    flat[numel] = float(n_local)
+    if flat.is_cuda and dist.get_backend(group) != "nccl":      # rehearsal backends (gloo): stage through the host
+        host = flat.cpu()
+        dist.all_reduce(host, group=group)
+        flat.copy_(host)
+    else:
+        dist.all_reduce(flat, group=group)
+    n = int(round(float(flat[numel].item())))
+    for r0, r1, off in blocks:
+        torch.mul(flat[off:off + (r1 - r0) * (C - r0)].view(r1 - r0, C - r0), 1.0 / n, out=H[r0:r1, r0:])
+    return n
+
+
+def plan_rows(bundles: Sequence[Tuple[int, int]], world: int, align: int = 128) -> List[List[Tuple[int, int, int]]]:
+    """bundles: (C, R) per distinct Hessian (R = stacked rows of the Linears that share it).  Returns, per bundle, the
+    slabs (rank, row_a, row_b) that cover its rows.  A bundle's ranks all replicate its factorization chain (it depends
+    on H only) and split its rows; with fewer ranks than bundles whole bundles are dealt by cost.  Deterministic."""
+    def chain(C):                       # seconds, roughly: latency-bound diagonal chain + 2/3 C^3 at ~80 TFLOP/s
+        return 1.0e-4 * (C / 128.0) + (2.0 / 3.0) * C ** 3 / 8e13
+    def loop_fixed(C):                  # the column loop's per-block latency does not shrink with fewer rows
+        return 6.5e-5 * (C / 128.0)
+    def rows_cost(C, R):
+        return R * float(C) ** 2 / 6e13
+    nb = len(bundles)
+    if nb == 0:
+        return []
+    if world < nb:
+        cost = [chain(C) + loop_fixed(C) + rows_cost(C, R) for C, R in bundles]
+        owner = assign_units(cost, world)
+        out: List[List[Tuple[int, int, int]]] = [[] for _ in bundles]
+        for r, idxs in enumerate(owner):
+            for b in idxs:
+                out[b] = [(r, 0, bundles[b][1])]
+        return out
+    k = [1] * nb
+    def t(b):
+        C, R = bundles[b]
+        return chain(C) + loop_fixed(C) + rows_cost(C, R) / k[b]
+    for _ in range(world - nb):
+        cand = [b for b in range(nb) if k[b] * align < bundles[b][1]]
+        if not cand:
+            break
+        b = max(cand, key=lambda j: (t(j), -j))
+        k[b] += 1
+    out, nxt = [], 0
+    for b, (C, R) in enumerate(bundles):
+        blocks = -(-R // align)
+        kk = min(k[b], blocks)
+        slabs, a = [], 0
+        for j in range(kk):
+            nbk = blocks // kk + (1 if j < blocks % kk else 0)
+            e = min(R, a + nbk * align)
+            slabs.append((nxt % world, a, e))
+            nxt += 1
+            a = e
+        out.append(slabs)
+    return out
+
+
+def fasterquant_sharded(solvers, bits: int, group=None, blocksize: int = 128, percdamp: float = .01,
+                        groupsize: int = -1, actorder: bool = False, static_groups: bool = False, timings=None):
+    """`fasterquant` of the Linears hooked in one forward pass, data-parallel over the ranks of `group`.
+
+    Every rank calls this with GPTQ objects for the SAME Linears (same order, same weights), each holding the Hessian
+    of the calibration samples THIS rank ran (add_batch).  Steps: (1) one all-reduce per distinct Hessian (Linears fed
+    the same tensor share one, gptq.SHARE_INPUT_HESSIANS); (2) `plan_rows`: every distinct Hessian's stacked rows are
+    split over ranks; (3) each rank runs gptq_fasterquant_rows on its slabs (the chain is replicated: it depends on
+    H only, which is bit-identical on all ranks after the all-reduce); (4) one fixed-size all-gather of the packed
+    rows, grids and per-row losses; (5) every rank rebuilds ALL the Linears from the packed form
+    (gptq_dequant_packed = the solver's own scale * (code - zero)), so the weights are bit-identical everywhere.
+    Publishes on every solver what `fasterquant` does (layer.weight, quantizer.scale / zero, error, perm, group
+    tables) plus `qweight`; returns [(qweight, scale_table [R, G], zero_table [R, G])] per solver."""
+    from . import gptq as gmod
+    from .quant import dequant_packed, pack_codes
+    if bits not in (3, 4):
+        raise NotImplementedError("sharded runs exchange packed weights: bits must be 3 or 4")
+    if groupsize > 0 and actorder and not static_groups:
+        raise NotImplementedError("sharded runs need static groups with act-order (no g_idx in the packed format)")
+    solvers = list(solvers)
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-
-    def payload(idx_list):
-        n = 0
-        for i in idx_list:
-            (qh, qw), (gr, gc) = packed_shapes(units[i], bits, groupsize)
-            n += qh * qw + 2 * gr * gc
-        return n
-
-    sizes = [payload(a) for a in assignment]
-    width = max(max(sizes), 1)
-    if device is None:
-        some = next(iter(local.values()))[0] if local else None
-        if some is None and dist.get_backend(group) == "nccl":
-            raise ValueError("allgather_packed: this rank owns no unit, pass device= (RCCL needs device buffers)")
-        device = some.device if some is not None else torch.device("cpu")
-    device = torch.device(device)
-    send = torch.zeros(width, dtype=torch.int32, device=device)
+    dev = solvers[0].dev
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    t0, t1, t2, t3 = ev(), ev(), ev(), ev()
+    # ---- distinct Hessians: a leader and the solvers that share its H ---------------------------------
+    gmod.flush_pending()
+    chosen = {id(s) for s in solvers}
+    bundles, seen = [], set()
+    for s in solvers:
+        L = s._leader or s
+        if id(L) in seen:
+            continue
+        seen.add(id(L))
+        members = [m for m in [L] + list(L._followers) if id(m) in chosen]
+        if L not in members:                    # the leader is not part of this call: members take their own copies
+            for m in members:
+                m._materialize()
+            for m in members:
+                bundles.append([m])
+                seen.add(id(m))
+            continue
+        for f in list(L._followers):
+            if id(f) not in chosen:
+                f._materialize()
+        bundles.append(members)
+    C_of = [b[0].columns for b in bundles]
+    R_of = [sum(m.rows for m in b) for b in bundles]
+    # ---- (1) all-reduce of H ---------------------------------------------------------------------------
+    t0.record()
+    for b in bundles:
+        L = b[0]
+        n = allreduce_hessian(L._H, L.nsamples, group)
+        for m in b:
+            m.nsamples = n
+            m._applied = n
+        L._lower_stale = True
+    t1.record()
+    # ---- (2) plan, (3) solve my slabs on up to SOLVE_STREAMS lanes -------------------------------------
+    plan = plan_rows(list(zip(C_of, R_of)), world)
+    cur = torch.cuda.current_stream(dev)
+    mine = [(bi, a, e) for bi, slabs in enumerate(plan) for (r, a, e) in slabs if r == rank]
+    pool = gmod._SOLVE_STREAMS.setdefault(dev, [])
+    want = max(1, min(int(gmod.SOLVE_STREAMS), len(mine)))
+    while len(pool) < want - 1:
+        pool.append(torch.cuda.Stream(device=dev))
+    lanes = [cur] + pool[:want - 1]
+    for st in lanes[1:]:
+        st.wait_stream(cur)
+    states = {}
+    order = sorted(mine, key=lambda t: -(C_of[t[0]] ** 3 + (t[2] - t[1]) * C_of[t[0]] ** 2))
+    for k, (bi, a, e) in enumerate(order):
+        b = bundles[bi]
+        W = _stacked_rows(b, a, e)
+        L = b[0]
+        H = L._H
+        st = lanes[k % want]
+        if st is not cur:
+            H.record_stream(st)
+            W.record_stream(st)
+        with torch.cuda.stream(st):
+            states[(bi, a, e)] = gmod._enqueue_rows(dev, W, H, L.quantizer, None, blocksize, percdamp, groupsize,
+                                                    actorder, static_groups)
+    for st in lanes[1:]:
+        cur.wait_stream(st)
+    for b in bundles:
+        for m in b:
+            m._H = None                          # consumed (or never needed on this rank)
+            if m._leader is not None:
+                m._leader = None
+        b[0]._followers = []
+    # ---- (4) all-gather of packed rows + grids + row losses ---------------------------------------------
+    def slab_numel(bi, a, e):
+        Cb = C_of[bi]
+        Gb = -(-Cb // groupsize) if groupsize > 0 else 1
+        return (Cb // 32 * bits) * (e - a) + (2 * Gb + 1) * (e - a) + (Cb if actorder else 0)
+    per_rank = [[(bi, a, e) for bi, slabs in enumerate(plan) for (r, a, e) in slabs if r == rr] for rr in range(world)]
+    width = max(1, max(sum(slab_numel(*t) for t in lst) for lst in per_rank))
+    send = torch.zeros(width, dtype=torch.int32, device=dev)
     off = 0
-    for i in assignment[rank]:
-        q, s, z = local[i]
-        for t in (q.reshape(-1), s.reshape(-1).float().view(torch.int32), z.reshape(-1).float().view(torch.int32)):
+    for key in per_rank[rank]:
+        st = states[key]
+        gmod._check_solved(st)
+        bi, a, e = key
+        if groupsize > 0:
+            stab, ztab = st["gscale"], st["gzero"]
+        else:
+            stab, ztab = st["scale"].reshape(-1, 1), st["zero"].reshape(-1, 1)
+        parts = [pack_codes(st["codes"], bits).reshape(-1), stab.reshape(-1).view(torch.int32),
+                 ztab.reshape(-1).view(torch.int32), st["row_loss"].view(torch.int32)]
+        if actorder:
+            parts.append(st["perm"])
+        for t in parts:
             send[off:off + t.numel()] = t
             off += t.numel()
-    if device.type == "cuda" and dist.get_backend(group) != "nccl":
-        # rehearsal backends (gloo): stage through host memory
+    t2.record()
+    if dist.get_backend(group) != "nccl":
         host = torch.empty(world * width, dtype=torch.int32)
         dist.all_gather_into_tensor(host, send.cpu(), group=group)
-        recv = host.to(device)
+        recv = host.to(dev)
     else:
-        recv = torch.empty(world * width, dtype=torch.int32, device=device)
+        recv = torch.empty(world * width, dtype=torch.int32, device=dev)
         dist.all_gather_into_tensor(recv, send, group=group)
-    out: Dict[int, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = {}
-    for r in range(world):
-        off = r * width
-        for i in assignment[r]:
-            (qh, qw), (gr, gc) = packed_shapes(units[i], bits, groupsize)
-            q = recv[off:off + qh * qw].reshape(qh, qw); off += qh * qw
-            s = recv[off:off + gr * gc].view(torch.float32).reshape(gr, gc); off += gr * gc
-            z = recv[off:off + gr * gc].view(torch.float32).reshape(gr, gc); off += gr * gc
-            out[i] = (q, s, z)
-    return out
+    # ---- (5) rebuild every Linear from the packed form --------------------------------------------------
+    full = []
+    for bi, b in enumerate(bundles):
+        Cb, Rb = C_of[bi], R_of[bi]
+        Gb = -(-Cb // groupsize) if groupsize > 0 else 1
+        full.append(dict(qw=torch.empty((Cb // 32 * bits, Rb), dtype=torch.int32, device=dev),
+                         s=torch.empty((Rb, Gb), device=dev), z=torch.empty((Rb, Gb), device=dev),
+                         loss=torch.empty(Rb, device=dev), perm=None))
+    for rr in range(world):
+        off = rr * width
+        for (bi, a, e) in per_rank[rr]:
+            Cb = C_of[bi]
+            Gb = -(-Cb // groupsize) if groupsize > 0 else 1
+            n = e - a
+            f = full[bi]
+            qh = Cb // 32 * bits
+            f["qw"][:, a:e] = recv[off:off + qh * n].view(qh, n); off += qh * n
+            f["s"][a:e] = recv[off:off + n * Gb].view(torch.float32).view(n, Gb); off += n * Gb
+            f["z"][a:e] = recv[off:off + n * Gb].view(torch.float32).view(n, Gb); off += n * Gb
+            f["loss"][a:e] = recv[off:off + n].view(torch.float32); off += n
+            if actorder:
+                f["perm"] = recv[off:off + Cb].clone(); off += Cb
+    results = {}
+    for bi, b in enumerate(bundles):
+        f = full[bi]
+        r0 = 0
+        for m in b:
+            r1 = r0 + m.rows
+            qw = f["qw"][:, r0:r1].contiguous()
+            stab, ztab = f["s"][r0:r1].contiguous(), f["z"][r0:r1].contiguous()
+            lin = m.layer
+            W = dequant_packed(qw, stab.t().contiguous(), ztab.t().contiguous(), bits, groupsize, dtype=lin.weight.dtype)
+            lin.weight.data = W.reshape(lin.weight.shape)
+            q = m.quantizer
+            q.maxq = q.maxq.to(dev)
+            q.scale = stab[:, -1:].clone()
+            q.zero = ztab[:, -1:].clone()
+            m.error = float(f["loss"][r0:r1].sum().item())
+            m.qweight = qw
+            m.codes = None
+            m.group_scale = stab if groupsize > 0 else None
+            m.group_zero = ztab if groupsize > 0 else None
+            m.perm = f["perm"]
+            m.static_groups = bool(static_groups)
+            m.Hinv = None
+            results[id(m)] = (qw, stab, ztab)
+            r0 = r1
+    t3.record()
+    if timings is not None:
+        torch.cuda.synchronize(dev)
+        timings["exchange"] = timings.get("exchange", 0.0) + t0.elapsed_time(t1) + t2.elapsed_time(t3)
+    return [results[id(s)] for s in solvers]
+
+
+def _stacked_rows(members, a: int, e: int) -> torch.Tensor:
+    """Rows [a, e) of the Linears `members` stacked on top of each other, fp32 contiguous (a fresh tensor)."""
+    parts, r0 = [], 0
+    for m in members:
+        r1 = r0 + m.rows
+        lo, hi = max(a, r0), min(e, r1)
+        if lo < hi:
+            parts.append(m.layer.weight.data[lo - r0:hi - r0].float())
+        r0 = r1
+    return (torch.cat(parts, 0) if len(parts) > 1 else parts[0].clone()).contiguous()

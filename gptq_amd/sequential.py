@@ -45,19 +45,10 @@ class QuantArgs:
     nearest: bool = False
     blocksize: int = 128
     hessian_defer: int = 16     # hook inputs folded into H per launch (gptq_amd.gptq.HESSIAN_DEFER)
-    row_slabs: int = 1          # multi-GPU only, gptq_amd.parallel.plan_units: 0 never, 1 when ranks would idle, k >= 2 always
 
 
 class _Stop(Exception):
     pass
-
-
-class _RowSlab(nn.Module):
-    """Rows [r0, r1) of a Linear's weight as a layer of its own (a view: same storage), for a row-slab GPTQ solve."""
-
-    def __init__(self, linear, r0, r1):
-        super().__init__()
-        self.weight = nn.Parameter(linear.weight.data[r0:r1], requires_grad=False)
 
 
 def _family(model):
@@ -121,27 +112,17 @@ def _run_layer(layer, x, kwargs):
     return out.reshape(x.shape)
 
 
-def _packed_tables(solver, groupsize):
-    """(scale, zero) tables [out, G] of a finished solver: per group, or per row (G = 1)."""
-    if groupsize > 0:
-        if solver.perm is not None and not solver.static_groups:
-            raise NotImplementedError("sharded runs need static groups with act-order (no g_idx in the packed format)")
-        return solver.group_scale, solver.group_zero
-    return solver.quantizer.scale.reshape(-1, 1).float(), solver.quantizer.zero.reshape(-1, 1).float()
-
-
 @torch.no_grad()
 def quantize_sequential(model, dataloader, dev, args: QuantArgs, group=None) -> Dict[str, Quantizer]:
     """GPTQ every Linear of every decoder block; returns {full_name: quantizer} like the reference.
 
-    With torch.distributed initialised (one process per GPU) the Linears hooked in the same forward
-    pass are dealt to the ranks by cost: every rank runs the (replicated) block
-    forward, but accumulates Hessians and solves only for ITS Linears; one all-gather of the packed
-    weights + grids per group, then every rank rebuilds all Linears from the packed form, so all ranks
-    hold bit-identical weights for the next forward pass."""
+    With torch.distributed initialised (one process per GPU) the run is DATA-PARALLEL over the calibration samples
+    (SURVEY section 8e): rank r captures and forwards only samples r, r + world, ... (so the block forwards are
+    sharded too, and no activation ever crosses a link), folds them into its Hessians, and
+    `parallel.fasterquant_sharded` does the rest per hooked group -- one all-reduce of H per distinct Hessian, the rows
+    of W split over the ranks, one all-gather of the packed rows + grids, every rank rebuilding ALL Linears from the
+    packed form, so all ranks hold bit-identical weights for the next forward pass."""
     import torch.distributed as dist
-    from . import parallel as par
-    from .quant import dequant_packed, pack_codes
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank(group) if world > 1 else 0
     if world > 1 and args.wbits not in (3, 4):
@@ -157,18 +138,20 @@ def quantize_sequential(model, dataloader, dev, args: QuantArgs, group=None) -> 
 
 
 def _quantize_sequential(model, dataloader, dev, args, group, world, rank):
-    import torch.distributed as dist  # noqa: F401
     from . import parallel as par
-    from .quant import dequant_packed, pack_codes
     use_cache = model.config.use_cache
     model.config.use_cache = False
     fam = _family(model)
     static_groups = args.static_groups if args.static_groups is not None else fam["kind"] == "opt"
     layers = fam["layers"]
-    inps, kwargs = _capture_layer0(model, fam, (b[0] for b in dataloader), args.nsamples, dev)
+    batches = [b[0] for b in dataloader][:args.nsamples]
+    mine = list(range(rank, len(batches), world))               # this rank's calibration samples
+    inps, kwargs = _capture_layer0(model, fam, (batches[j] for j in mine), len(mine), dev)
     outs = torch.zeros_like(inps)
     quantizers: Dict[str, Quantizer] = {}
     records: List[dict] = []
+    kw = dict(blocksize=args.blocksize, percdamp=args.percdamp, groupsize=args.groupsize, actorder=args.act_order,
+              static_groups=static_groups)
     for i in range(len(layers)):
         layer = layers[i].to(dev)
         full = find_layers(layer)
@@ -180,77 +163,32 @@ def _quantize_sequential(model, dataloader, dev, args, group, world, rank):
         else:
             groups = [list(full.keys())]
         for names in groups:
-            units, assignment = None, None
-            if world > 1:
-                units, _, assignment = par.plan_units([(n, full[n].out_features, full[n].in_features) for n in names], world,
-                                                      args.nsamples, model.seqlen, args.blocksize, args.row_slabs)
-                mine = list(assignment[rank])
-            else:
-                units = [par.Unit(n, full[n].out_features, full[n].in_features) for n in names]
-                mine = list(range(len(units)))
-            solvers = {}                                        # unit index -> GPTQ
-            for k in mine:
-                u = units[k]
-                target = full[u.name] if not u.full_rows else _RowSlab(full[u.name], u.row0, u.row0 + u.rows)
-                solvers[k] = GPTQ(target)
-                solvers[k].quantizer = Quantizer()
-                solvers[k].quantizer.configure(args.wbits, perchannel=True, sym=args.sym, mse=False)
-            by_module = {}
-            for k in mine:
-                by_module.setdefault(units[k].name, []).append(solvers[k])
+            solvers = {}
+            for n in names:
+                solvers[n] = GPTQ(full[n])
+                solvers[n].quantizer = Quantizer()
+                solvers[n].quantizer.configure(args.wbits, perchannel=True, sym=args.sym, mse=False)
 
             def hook(name):
                 def fn(_, inp, out):
-                    for sv in by_module[name]:                  # slabs of one Linear share its input (and its Hessian)
-                        sv.add_batch(inp[0].data, out.data)
+                    solvers[name].add_batch(inp[0].data, out.data)
                 return fn
 
-            handles = [full[name].register_forward_hook(hook(name)) for name in by_module]
-            for j in range(args.nsamples):
+            handles = [full[n].register_forward_hook(hook(n)) for n in names]
+            for j in range(len(mine)):
                 outs[j] = _run_layer(layer, inps[j], kwargs)
             for h in handles:
                 h.remove()
-            fasterquant_many(list(solvers.values()), blocksize=args.blocksize, percdamp=args.percdamp,
-                             groupsize=args.groupsize, actorder=args.act_order, static_groups=static_groups)
-            for k in mine:
-                u = units[k]
-                key = f"{fam['prefix']}.{i}.{u.name}"
-                if not u.full_rows:
-                    quantizers[key] = solvers[k].quantizer
-                records.append(dict(name=key if not u.full_rows else f"{key}[{u.row0}:{u.row0 + u.rows}]",
-                                    error=solvers[k].error))
-                if world == 1:
-                    solvers[k].free()
             if world > 1:
-                local = {}
-                for k in mine:
-                    sv = solvers[k]
-                    st, zt = _packed_tables(sv, args.groupsize)
-                    local[k] = (pack_codes(sv.codes, args.wbits), st.contiguous(), zt.contiguous())
-                    sv.free()
-                everything = par.allgather_packed(local, units, assignment, args.wbits, args.groupsize, group=group,
-                                                  device=dev)
-                grids = {}                                      # name -> [(row0, scale col, zero col)] of gathered slabs
-                for k, u in enumerate(units):
-                    qw, st, zt = everything[k]
-                    lin = full[u.name]
-                    W = dequant_packed(qw.to(dev), st.t().contiguous().to(dev), zt.t().contiguous().to(dev),
-                                       args.wbits, args.groupsize, dtype=lin.weight.dtype)
-                    if u.full_rows:
-                        lin.weight.data[u.row0:u.row0 + u.rows] = W
-                    else:
-                        lin.weight.data = W
-                    grids.setdefault(u.name, []).append((u.row0, st[:, -1:].clone(), zt[:, -1:].clone()))
-                for name, parts in grids.items():
-                    key = f"{fam['prefix']}.{i}.{name}"
-                    if key not in quantizers:                   # grids of Linears (or slabs) other ranks solved
-                        parts.sort(key=lambda t: t[0])
-                        q = Quantizer()
-                        q.configure(args.wbits, perchannel=True, sym=args.sym, mse=False)
-                        q.scale = torch.cat([p[1] for p in parts], 0)
-                        q.zero = torch.cat([p[2] for p in parts], 0)
-                        quantizers[key] = q
-        for j in range(args.nsamples):                        # opt.py:216-217: next block sees quantized outputs
+                par.fasterquant_sharded([solvers[n] for n in names], bits=args.wbits, group=group, **kw)
+            else:
+                fasterquant_many([solvers[n] for n in names], **kw)
+            for n in names:
+                key = f"{fam['prefix']}.{i}.{n}"
+                quantizers[key] = solvers[n].quantizer
+                records.append(dict(name=key, error=solvers[n].error))
+                solvers[n].free()
+        for j in range(len(mine)):                            # opt.py:216-217: next block sees quantized outputs
             outs[j] = _run_layer(layer, inps[j], kwargs)
         layers[i] = layer.cpu()
         del layer

@@ -375,8 +375,11 @@ def test_fasterquant_mid1024_reference_flag_sets(G, name):
                   hessian="accumulated on the GPU from the stored fp16 samples")
     print(f"{name}: relFro {rel:.2e}, flipped codes {flipped}/{R * C} ({flipped / (R * C):.1e}), rows identical "
           f"{rows_same}/{R}, error rel {err_rel:.1e}")
-    assert rel <= 1e-3 and err_rel <= 1e-3
+    # a flipped code moves one weight by a whole grid step (and usually drags a few later columns of ITS row along), so
+    # rel-Fro is sqrt(flips) * step / |Q|: 1e-3 holds only while nothing flips; the count is the real bar
+    assert rel <= 3e-3 and err_rel <= 1e-3
     assert flipped <= MID_MAX_FLIPPED[name]
+    assert rows_same >= R - 4
 
 
 def test_fasterquant_mid512_codes(G):
