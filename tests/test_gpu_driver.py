@@ -172,59 +172,95 @@ def test_pack_save_load_generate_roundtrip(hip_device, tmp_path):
     assert abs(ppl_packed - ppl_dense) <= 2e-2 * ppl_dense
 
 
-def _sharded_worker(rank, world, port, out_path, row_slabs=1):
+def _sharded_worker(rank, world, port, out_path, kind):
     import os
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)     # both ranks share cuda:0 on the 1-GPU box
     try:
         import gptq_amd.gptq as gmod
-        from gptq_amd.sequential import QuantArgs, opt_sequential
+        from gptq_amd.sequential import llama_sequential, opt_sequential
         gmod.VERBOSE = False
         dev = torch.device("cuda:0")
-        model, calib = _sharding_case()
-        opt_sequential(model, calib, dev, QuantArgs(wbits=4, nsamples=8, groupsize=32, static_groups=True,
-                                                    row_slabs=row_slabs))
+        model, calib, args, seq = _sharding_case(kind)
+        quantizers = (opt_sequential if seq == "opt" else llama_sequential)(model, calib, dev, args)
+        recs = opt_sequential.__globals__["quantize_sequential"].last_records
         if rank == 0:
-            torch.save({k: v.cpu() for k, v in model.state_dict().items()}, out_path)
+            torch.save({"sd": {k: v.cpu() for k, v in model.state_dict().items()},
+                        "errors": [r["error"] for r in recs],
+                        "scales": {k: q.scale.cpu() for k, q in quantizers.items()}}, out_path)
+        # every rank must hold the same weights: compare a checksum of everything
+        chk = torch.stack([v.double().sum() for v in model.state_dict().values()]).sum().reshape(1).cpu()
+        both = [torch.empty_like(chk) for _ in range(world)]
+        dist.all_gather(both, chk)
+        assert all(torch.equal(b, both[0]) for b in both), "ranks disagree on the quantized model"
     finally:
         dist.destroy_process_group()
 
 
-def _sharding_case():
-    from transformers import OPTConfig, OPTForCausalLM
-    cfg = OPTConfig(vocab_size=256, hidden_size=128, ffn_dim=512, num_hidden_layers=2, num_attention_heads=4,
-                    max_position_embeddings=128, word_embed_proj_dim=128, do_layer_norm_before=True,
-                    dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, layerdrop=0.0)
-    torch.manual_seed(0)
-    model = OPTForCausalLM(cfg).half().eval()
-    model.seqlen = 128
+def _sharding_case(kind):
+    from gptq_amd.sequential import QuantArgs
     gen = torch.Generator().manual_seed(4)
-    calib = [(torch.randint(0, 256, (1, 128), generator=gen), None) for _ in range(8)]
-    return model, calib
+    if kind == "opt_g32":
+        from transformers import OPTConfig, OPTForCausalLM
+        cfg = OPTConfig(vocab_size=256, hidden_size=128, ffn_dim=512, num_hidden_layers=2, num_attention_heads=4,
+                        max_position_embeddings=128, word_embed_proj_dim=128, do_layer_norm_before=True,
+                        dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, layerdrop=0.0)
+        torch.manual_seed(0)
+        model = OPTForCausalLM(cfg).half().eval()
+        model.seqlen = 128
+        calib = [(torch.randint(0, 256, (1, 128), generator=gen), None) for _ in range(8)]
+        return model, calib, QuantArgs(wbits=4, nsamples=8, groupsize=32, static_groups=True), "opt"
+    from transformers import LlamaConfig, LlamaForCausalLM
+    cfg = LlamaConfig(vocab_size=256, hidden_size=256, intermediate_size=704, num_hidden_layers=2,
+                      num_attention_heads=4, num_key_value_heads=4, max_position_embeddings=256)
+    torch.manual_seed(0)
+    model = LlamaForCausalLM(cfg).half().eval()
+    model.seqlen = 256
+    calib = [(torch.randint(0, 256, (1, 256), generator=gen), None) for _ in range(7)]     # 7: uneven split over 2 ranks
+    return model, calib, QuantArgs(wbits=4, nsamples=7, act_order=True, true_sequential=True), "llama"
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("row_slabs", [1, 2])
-def test_module_sharded_two_ranks_match_single_process(hip_device, tmp_path, row_slabs):
-    """SURVEY 8e at driver level: 2 ranks (sharing the one GPU of the test box, gloo rendezvous) deal the
-    Linears of every block between them -- whole (row_slabs=1) or as row slabs (row_slabs=2: every Linear cut in
-    two, each half solved by one rank with the full Hessian) -- all-gather the packed weights and rebuild the
-    block; the result must equal the single-process quantization bit for bit."""
+@pytest.mark.parametrize("kind", ["opt_g32", "llama_actorder_trueseq"])
+def test_data_parallel_two_ranks_match_single_process(hip_device, tmp_path, kind):
+    """SURVEY 8e at driver level: 2 ranks (sharing the one GPU of the test box, gloo rendezvous) run the data-parallel
+    path -- each rank forwards and folds its share of the calibration samples, all-reduce of H, the rows of every
+    Linear split between the ranks, all-gather of the packed rows, every rank rebuilding every Linear.  The all-reduced
+    H equals the single-process running mean to fp32 rounding (not bit for bit), so the bar is the solver's own
+    end-to-end tolerance: few flipped codes, `error` scalars within 1e-3 (first block: identical inputs)."""
     import socket
     import torch.multiprocessing as mp
     import gptq_amd.gptq as gmod
-    from gptq_amd.sequential import QuantArgs, opt_sequential
+    from gptq_amd.sequential import llama_sequential, opt_sequential
     gmod.VERBOSE = False
-    model, calib = _sharding_case()
-    opt_sequential(model, calib, hip_device, QuantArgs(wbits=4, nsamples=8, groupsize=32, static_groups=True))
+    model, calib, args, seq = _sharding_case(kind)
+    fn = opt_sequential if seq == "opt" else llama_sequential
+    quantizers = fn(model, calib, hip_device, args)
     ref = {k: v.cpu() for k, v in model.state_dict().items()}
+    ref_err = [r["error"] for r in opt_sequential.__globals__["quantize_sequential"].last_records]
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / "sharded.pt")
-    mp.spawn(_sharded_worker, args=(2, port, out, row_slabs), nprocs=2, join=True)
+    mp.spawn(_sharded_worker, args=(2, port, out, kind), nprocs=2, join=True)
     got = torch.load(out, weights_only=True)
-    assert got.keys() == ref.keys()
-    for k in ref:
-        assert torch.equal(got[k], ref[k]), k
+    assert got["sd"].keys() == ref.keys()
+    per_block = len(ref_err) // 2
+    errs = np.array(got["errors"])
+    # identical inputs only for the first hooked group of the first block (true-sequential: k/v/q); later groups see
+    # activations downstream of weights in which an occasional code flipped
+    first = per_block if seq == "opt" else 3
+    assert np.allclose(errs[:first], ref_err[:first], rtol=1e-3), (errs[:first], ref_err[:first])
+    assert np.allclose(errs[first:], ref_err[first:], rtol=5e-2)
+    worst, flipped_frac = 0.0, 0.0
+    for name, q in quantizers.items():
+        a, b = got["sd"][name + ".weight"].float(), ref[name + ".weight"].float()
+        rel = float((a - b).norm() / b.norm())
+        worst = max(worst, rel)
+        frac = float((a != b).float().mean())
+        if ".layers.0." in name and (seq == "opt" or any(t in name for t in ("q_proj", "k_proj", "v_proj"))):
+            assert frac <= 2e-3, (name, frac)        # same inputs on both runs
+        flipped_frac = max(flipped_frac, frac)
+    print(f"{kind}: 2-rank data-parallel vs single process: worst Q rel-Fro {worst:.2e}, worst changed fraction {flipped_frac:.2e}")
+    assert worst <= 1e-1

@@ -286,7 +286,7 @@ def _run_gptq(G, W, H, n, *, bits, sym, dtype=torch.float32, **kw):
 # Flipped integer codes allowed per reference fixture (out of R*C = 8192 ... 30720 codes).  OBSERVED on MI355X
 # (profiles/r02_parity.json): see the table there; the bound is the observed count + a margin of 2 for box-to-box
 # variation of nothing but the order of fp32 sums in the factorization chain and the trailing GEMMs.
-MAX_FLIPPED_DEFAULT = 16
+MAX_FLIPPED_DEFAULT = 2          # observed on every one of the 19 fixtures: 0 (bit-identical codes and weights)
 MAX_FLIPPED = {}
 
 
@@ -341,7 +341,8 @@ def test_fasterquant_vs_reference_golden(G, name):
 # Mid-size reference runs with the flag sets the BASELINE configs use (oracle/gen_golden_mid.py): the real calling
 # sequence -- fp16 Linear, add_batch from the stored fp16 calibration samples, fasterquant -- against the reference's
 # codes and grids.  Flipped-code bound per fixture: observed count (profiles/r02_parity.json) + margin.
-MID_MAX_FLIPPED = {"g5_mid1024_g128_static": 64, "g5_mid1024_actorder": 64, "g5_mid1024_3bit": 64}
+# observed: g128_static 12 flips (all in ONE row), actorder 0, 3bit 0 of 1,048,576 codes each
+MID_MAX_FLIPPED = {"g5_mid1024_g128_static": 48, "g5_mid1024_actorder": 16, "g5_mid1024_3bit": 16}
 
 
 @pytest.mark.parametrize("name", ["g5_mid1024_g128_static", "g5_mid1024_actorder", "g5_mid1024_3bit"])
@@ -548,24 +549,27 @@ def test_joint_solve_of_shared_hessian_objects_matches_separate_solves(G, kw):
 def test_shared_input_hessians_leader_freed_or_solved_first(G):
     gm = G.gptq
     gm.VERBOSE = False
-    objs, xs = _shared_setup(G, n=3)
-    for k in range(3):
-        for o in objs:
-            o.add_batch(xs[k], None)
-    gm.flush_pending()
-    assert objs[1]._leader is objs[0] and objs[2]._leader is objs[0]
-    ref = None
-    objs[0].fasterquant(blocksize=128, percdamp=0.01)          # leader consumes (overwrites) its H
-    assert objs[1]._leader is None and objs[2]._leader is None and not objs[0]._followers
-    objs[0].free()
-    H1, H2 = objs[1].H.clone(), objs[2].H.clone()
-    assert torch.equal(H1, H2)
-    X = torch.cat([x[0] for x in xs[:3]], 0).double()
-    ref = (2.0 / 3.0) * (X.t() @ X)
-    assert relfro(H1.double().cpu(), ref.cpu()) < 1e-6
-    G.fasterquant_many(objs[1:], blocksize=128, percdamp=0.01)
-    assert torch.equal(objs[1].quantizer.scale, objs[1].quantizer.scale)
-    assert objs[1].error > 0 and objs[2].error > 0
+    old = gm.HESSIAN_DEFER
+    gm.HESSIAN_DEFER = 4                                       # sharing needs deferral (defer 1 launches inside add_batch)
+    try:
+        objs, xs = _shared_setup(G, n=3)
+        for k in range(3):
+            for o in objs:
+                o.add_batch(xs[k], None)
+        gm.flush_pending()
+        assert objs[1]._leader is objs[0] and objs[2]._leader is objs[0]
+        objs[0].fasterquant(blocksize=128, percdamp=0.01)      # leader consumes (overwrites) its H
+        assert objs[1]._leader is None and objs[2]._leader is None and not objs[0]._followers
+        objs[0].free()
+        H1, H2 = objs[1].H.clone(), objs[2].H.clone()
+        assert torch.equal(H1, H2)
+        X = torch.cat([x[0] for x in xs[:3]], 0).double()
+        ref = (2.0 / 3.0) * (X.t() @ X)
+        assert relfro(H1.double().cpu(), ref.cpu()) < 1e-6
+        G.fasterquant_many(objs[1:], blocksize=128, percdamp=0.01)
+        assert objs[1].error > 0 and objs[2].error > 0
+    finally:
+        gm.HESSIAN_DEFER = old
 
 
 # ----------------------------------------------------------------- a9 / a12 pack
