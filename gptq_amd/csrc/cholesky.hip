@@ -285,22 +285,30 @@ __global__ __launch_bounds__(GEMM_THREADS) void panel_kernel(float* __restrict__
   gemm_tile<float, float, true, true>(a, b, 0, NB, smem, Epilogue{P, Cp, 1, EPI_STORE, TRI_ALL, 0.f, 0.f});
 }
 
-// Trailing update:  A[m][n] -= sum_k P[m][k] P[n][k]  on the lower tiles of the remaining matrix.
-// `first` offsets the linear tile id: ids [0, nrem) are the tiles of the next block column, which the look-ahead
-// schedule updates on its own so that the next factorization + panel solve can start early.
-__global__ __launch_bounds__(GEMM_THREADS) void syrk_kernel(float* __restrict__ A, int Cp, int kb, int nrem,
-                                                            int first) {
+// Trailing update:  A[m][n] -= sum_{k in [k0, k0 + K)} L[m][k] L[n][k]  on the lower tiles (tm >= tn) of the block
+// columns tn in [tn0, tn1), all block rows down to nblk.  L's columns k0 .. k0 + K are final (panel solved).
+// Two levels, like the column loop's trailing updates: after every 128-column step only the rest of the current
+// OUTER panel of CSUPER block columns is updated (K = 128, critical path); once per outer panel everything beyond
+// it gets ONE rank-(CSUPER * 128) update.
+constexpr int CSUPER = 4;
+__global__ __launch_bounds__(GEMM_THREADS) void syrk_kernel(float* __restrict__ A, int Cp, int nblk, int k0, int K,
+                                                            int tn0, int tn1) {
   __shared__ __attribute__((aligned(16))) float smem[GEMM_LDS_FLOATS];
-  int rest = blockIdx.x + first, tn = 0;   // column tile tn, row tile tm >= tn
-  while (rest >= nrem - tn) { rest -= nrem - tn; ++tn; }
+  int rest = blockIdx.x, tn = tn0;             // column tile tn, row tile tm >= tn
+  while (rest >= nblk - tn) { rest -= nblk - tn; ++tn; }
+  if (tn >= tn1) return;
   const int tm = tn + rest;
-  const long r0 = (long)(kb + 1 + tm) * NB, c0 = (long)(kb + 1 + tn) * NB;
-  Operand<float> a{A + r0 * Cp + (long)kb * NB, Cp, 1, NB, true};
-  Operand<float> b{A + c0 * Cp + (long)kb * NB, Cp, 1, NB, true};
+  const long r0 = (long)tm * NB, c0 = (long)tn * NB;
+  Operand<float> a{A + r0 * Cp + k0, Cp, 1, NB, true};
+  Operand<float> b{A + c0 * Cp + k0, Cp, 1, NB, true};
   float* Ct = A + r0 * Cp + c0;
   const bool diag = tm == tn;
-  gemm_tile<float, float, true, true>(a, b, 0, NB, smem,
+  gemm_tile<float, float, true, true>(a, b, 0, K, smem,
                                       Epilogue{Ct, Cp, 1, EPI_SUB, diag ? TRI_LOWER : TRI_ALL, 0.f, 0.f});
+}
+static inline int syrk_tiles(int nblk, int tn0, int tn1) {       // sum_{tn in [tn0, tn1)} (nblk - tn)
+  const int n = tn1 - tn0;
+  return n <= 0 ? 0 : n * nblk - (tn0 + tn1 - 1) * n / 2;
 }
 
 // Recursive-doubling inverse, level with segment size s (in 128-blocks).  For every pair
@@ -312,7 +320,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void trtri_step1_kernel(const float* 
                                                                    float* __restrict__ Linv, int Cp,
                                                                    int nblk, int s, int p0) {
   __shared__ __attribute__((aligned(16))) float smem[GEMM_LDS_FLOATS];
-  const int p = blockIdx.y + p0, ti = blockIdx.x / s, tj = blockIdx.x % s;
+  // tiles with the longest K range (small tj) come first in dispatch order: the level ends without a long tail
+  const int p = blockIdx.y + p0, tj = blockIdx.x / s, ti = blockIdx.x % s;
   const int a0 = 2 * p * s, cb0 = a0 + s;
   if (cb0 + ti >= nblk) return;
   const long rm = (long)(cb0 + ti) * NB, cn = (long)(a0 + tj) * NB, ka = (long)a0 * NB;
@@ -328,7 +337,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void trtri_step1_kernel(const float* 
 __global__ __launch_bounds__(GEMM_THREADS) void trtri_step2_kernel(float* __restrict__ Linv, int Cp,
                                                                    int nblk, int s, int p0) {
   __shared__ __attribute__((aligned(16))) float smem[GEMM_LDS_FLOATS];
-  const int p = blockIdx.y + p0, ti = blockIdx.x / s, tj = blockIdx.x % s;
+  // K = (ti + 1) * 128: the bottom rows first
+  const int p = blockIdx.y + p0, ti = s - 1 - blockIdx.x / s, tj = blockIdx.x % s;
   const int a0 = 2 * p * s, cb0 = a0 + s;
   if (cb0 + ti >= nblk) return;
   const long rm = (long)(cb0 + ti) * NB, cn = (long)(a0 + tj) * NB, kc = (long)cb0 * NB;
@@ -380,9 +390,9 @@ extern "C" int gptq_hinv_upper(float* H, int ldh, int C, float percdamp, const i
 
   diag_mean_kernel<<<1, 256, 0, s>>>(H, ldh, C, percdamp, damp, info);
   build_abar_kernel<<<dim3(cdiv(Cp, 256), Cp), 256, 0, s>>>(H, ldh, C, Cp, perm, damp, A);
-  // Look-ahead: the factorization and the panel solve of block column kb+1 only need that column, so it is
-  // updated on the caller's stream right after panel kb and the rest of the trailing SYRK runs on a helper
-  // stream underneath them (they are serial and latency-bound).
+  // Look-ahead: the far update of an outer panel is split into "the next outer panel's block columns" (caller's stream:
+  // the factorization needs them next) and "everything beyond" (helper stream, underneath the next outer panel's steps,
+  // which are serial and latency-bound).
   SideCtx* sc = (lookahead_mask() & 1) ? side_ctx(s) : nullptr;
   bool side_busy = false;
 #ifdef GPTQ_DIAG   // timing-only ablation (wrong results): diagnostic library only
@@ -392,27 +402,36 @@ extern "C" int gptq_hinv_upper(float* H, int ldh, int C, float percdamp, const i
 #endif
   GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_inv_diag_v2_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_V2_LDS));
-  for (int kb = 0; kb < nblk; ++kb) {
-    potrf_inv_diag_v2_kernel<<<1, 512, POTRF_V2_LDS, s>>>(A, Linv, Cp, kb, info, potrf_abl);
-    const int nrem = nblk - kb - 1;
-    if (nrem <= 0) break;
-    panel_kernel<<<nrem, GEMM_THREADS, 0, s>>>(A, Linv, Cp, kb);
-    const int ntiles = nrem * (nrem + 1) / 2;
-    if (sc && ntiles > nrem) {
-      // block column kb+1 (tile ids [0, nrem)) is all the next factorization + panel need: it stays on the
-      // caller's stream; the other columns are updated on the helper stream under them.  Column kb+1 was last
-      // written by the previous step's helper part, hence the wait.
-      if (side_busy) GPTQ_CHECK_HIP(hipStreamWaitEvent(s, sc->side_done, 0));
-      syrk_kernel<<<nrem, GEMM_THREADS, 0, s>>>(A, Cp, kb, nrem, 0);
-      GPTQ_CHECK_HIP(hipEventRecord(sc->main_done, s));
-      GPTQ_CHECK_HIP(hipStreamWaitEvent(sc->stream, sc->main_done, 0));
-      syrk_kernel<<<ntiles - nrem, GEMM_THREADS, 0, sc->stream>>>(A, Cp, kb, nrem, nrem);
-      GPTQ_CHECK_HIP(hipEventRecord(sc->side_done, sc->stream));
-      side_busy = true;
-    } else {
-      if (side_busy) GPTQ_CHECK_HIP(hipStreamWaitEvent(s, sc->side_done, 0));
-      syrk_kernel<<<ntiles, GEMM_THREADS, 0, s>>>(A, Cp, kb, nrem, 0);
-      side_busy = false;
+  for (int p0 = 0; p0 < nblk; p0 += CSUPER) {
+    const int p1 = std::min(p0 + CSUPER, nblk);
+    for (int kb = p0; kb < p1; ++kb) {
+      potrf_inv_diag_v2_kernel<<<1, 512, POTRF_V2_LDS, s>>>(A, Linv, Cp, kb, info, potrf_abl);
+      const int nrem = nblk - kb - 1;
+      if (nrem <= 0) break;
+      panel_kernel<<<nrem, GEMM_THREADS, 0, s>>>(A, Linv, Cp, kb);
+      if (kb + 1 < p1)                                             // the rest of this outer panel: rank-128
+        syrk_kernel<<<syrk_tiles(nblk, kb + 1, p1), GEMM_THREADS, 0, s>>>(A, Cp, nblk, kb * NB, NB, kb + 1, p1);
+    }
+    if (p1 < nblk) {                                               // everything beyond: rank-((p1 - p0) * 128)
+      if (side_busy) {                                             // the previous far update wrote these tiles too
+        GPTQ_CHECK_HIP(hipStreamWaitEvent(s, sc->side_done, 0));
+        side_busy = false;
+      }
+      const int q1 = std::min(p1 + CSUPER, nblk);
+      syrk_kernel<<<syrk_tiles(nblk, p1, q1), GEMM_THREADS, 0, s>>>(A, Cp, nblk, p0 * NB, (p1 - p0) * NB, p1, q1);
+      if (q1 < nblk) {
+        hipStream_t ts = s;
+        if (sc) {
+          GPTQ_CHECK_HIP(hipEventRecord(sc->main_done, s));
+          GPTQ_CHECK_HIP(hipStreamWaitEvent(sc->stream, sc->main_done, 0));
+          ts = sc->stream;
+        }
+        syrk_kernel<<<syrk_tiles(nblk, q1, nblk), GEMM_THREADS, 0, ts>>>(A, Cp, nblk, p0 * NB, (p1 - p0) * NB, q1, nblk);
+        if (sc) {
+          GPTQ_CHECK_HIP(hipEventRecord(sc->side_done, sc->stream));
+          side_busy = true;
+        }
+      }
     }
   }
   if (side_busy) GPTQ_CHECK_HIP(hipStreamWaitEvent(s, sc->side_done, 0));
