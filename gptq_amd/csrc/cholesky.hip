@@ -9,7 +9,7 @@
 // All arithmetic is IEEE fp32 (no TF32/bf16), like gptq.py:18-19.
 #include <stdlib.h>
 
-#include "gemm_f32.h"
+#include "gemm2_f32.h"
 
 namespace gptq {
 
@@ -293,18 +293,23 @@ __global__ __launch_bounds__(GEMM_THREADS) void panel_kernel(float* __restrict__
 constexpr int CSUPER = 4;
 __global__ __launch_bounds__(GEMM_THREADS) void syrk_kernel(float* __restrict__ A, int Cp, int nblk, int k0, int K,
                                                             int tn0, int tn1) {
-  __shared__ __attribute__((aligned(16))) float smem[GEMM_LDS_FLOATS];
-  int rest = blockIdx.x, tn = tn0;             // column tile tn, row tile tm >= tn
+  // 64 x 64 output tiles (gemm2_f32.h): blockIdx.y selects the quarter (sm, sn) of a 128 x 128 block.  Measured on
+  // the launches of one step (31 ... 255 blocks): up to 2x faster than one workgroup per block, bit-identical.
+  __shared__ __attribute__((aligned(16))) float smem[GEMM64_LDS_FLOATS];
+  int rest = blockIdx.x, tn = tn0;             // column block tn, row block tm >= tn
   while (rest >= nblk - tn) { rest -= nblk - tn; ++tn; }
   if (tn >= tn1) return;
   const int tm = tn + rest;
-  const long r0 = (long)tm * NB, c0 = (long)tn * NB;
-  Operand<float> a{A + r0 * Cp + k0, Cp, 1, NB, true};
-  Operand<float> b{A + c0 * Cp + k0, Cp, 1, NB, true};
+  const int sm = blockIdx.y >> 1, sn = blockIdx.y & 1;
+  const bool diag_blk = tm == tn;
+  if (diag_blk && sm < sn) return;             // strictly upper quarter of a diagonal block
+  const long r0 = (long)tm * NB + 64 * sm, c0 = (long)tn * NB + 64 * sn;
+  Operand<float> a{A + r0 * Cp + k0, Cp, 1, 64, true};
+  Operand<float> b{A + c0 * Cp + k0, Cp, 1, 64, true};
   float* Ct = A + r0 * Cp + c0;
-  const bool diag = tm == tn;
-  gemm_tile<float, float, true, true>(a, b, 0, K, smem,
-                                      Epilogue{Ct, Cp, 1, EPI_SUB, diag ? TRI_LOWER : TRI_ALL, 0.f, 0.f});
+  const bool diag = diag_blk && sm == sn;
+  gemm_tile64<float, float, true, true>(a, b, 0, K, smem,
+                                        Epilogue{Ct, Cp, 1, EPI_SUB, diag ? TRI_LOWER : TRI_ALL, 0.f, 0.f});
 }
 static inline int syrk_tiles(int nblk, int tn0, int tn1) {       // sum_{tn in [tn0, tn1)} (nblk - tn)
   const int n = tn1 - tn0;
@@ -319,34 +324,37 @@ static inline int syrk_tiles(int nblk, int tn0, int tn1) {       // sum_{tn in [
 __global__ __launch_bounds__(GEMM_THREADS) void trtri_step1_kernel(const float* __restrict__ L,
                                                                    float* __restrict__ Linv, int Cp,
                                                                    int nblk, int s, int p0) {
-  __shared__ __attribute__((aligned(16))) float smem[GEMM_LDS_FLOATS];
-  // tiles with the longest K range (small tj) come first in dispatch order: the level ends without a long tail
+  __shared__ __attribute__((aligned(16))) float smem[GEMM64_LDS_FLOATS];
+  // tiles with the longest K range (small tj) come first in dispatch order: the level ends without a long tail;
+  // blockIdx.z = quarter (sm, sn) of the 128 x 128 block (64 x 64 output tiles, gemm2_f32.h)
   const int p = blockIdx.y + p0, tj = blockIdx.x / s, ti = blockIdx.x % s;
   const int a0 = 2 * p * s, cb0 = a0 + s;
   if (cb0 + ti >= nblk) return;
-  const long rm = (long)(cb0 + ti) * NB, cn = (long)(a0 + tj) * NB, ka = (long)a0 * NB;
-  Operand<float> a{L + rm * Cp + ka, Cp, 1, NB, true};            // B[m][k]
-  Operand<float> b{Linv + ka * Cp + cn, 1, Cp, NB, true};         // Ainv[k][n], lower: k >= n
+  const int sm = blockIdx.z >> 1, sn = blockIdx.z & 1;
+  const long rm = (long)(cb0 + ti) * NB + 64 * sm, cn = (long)(a0 + tj) * NB + 64 * sn, ka = (long)a0 * NB;
+  Operand<float> a{L + rm * Cp + ka, Cp, 1, 64, true};            // B[m][k]
+  Operand<float> b{Linv + ka * Cp + cn, 1, Cp, 64, true};         // Ainv[k][n], lower: k >= n
   float* Tt = Linv + cn * Cp + rm;                                // T^T lives at [n][m]
   // T^T[n][m] = sum_k Ainv[k][n] * B[m][k]: the operands swap roles so that the tile comes out already transposed
   // and its rows (m contiguous) are stored coalesced; products commute, so the bits are those of B * Ainv
-  gemm_tile<float, float, false, true>(b, a, tj * NB, s * NB, smem,
-                                       Epilogue{Tt, Cp, 1, EPI_STORE, TRI_ALL, 0.f, 0.f});
+  gemm_tile64<float, float, false, true>(b, a, tj * NB + 64 * sn, s * NB, smem,
+                                         Epilogue{Tt, Cp, 1, EPI_STORE, TRI_ALL, 0.f, 0.f});
 }
 
 __global__ __launch_bounds__(GEMM_THREADS) void trtri_step2_kernel(float* __restrict__ Linv, int Cp,
                                                                    int nblk, int s, int p0) {
-  __shared__ __attribute__((aligned(16))) float smem[GEMM_LDS_FLOATS];
-  // K = (ti + 1) * 128: the bottom rows first
+  __shared__ __attribute__((aligned(16))) float smem[GEMM64_LDS_FLOATS];
+  // K = (ti + 1) * 128: the bottom rows first; blockIdx.z = quarter (sm, sn) of the 128 x 128 block
   const int p = blockIdx.y + p0, ti = s - 1 - blockIdx.x / s, tj = blockIdx.x % s;
   const int a0 = 2 * p * s, cb0 = a0 + s;
   if (cb0 + ti >= nblk) return;
-  const long rm = (long)(cb0 + ti) * NB, cn = (long)(a0 + tj) * NB, kc = (long)cb0 * NB;
-  Operand<float> a{Linv + rm * Cp + kc, Cp, 1, NB, true};         // Cinv[m][k], lower: k <= m
-  Operand<float> b{Linv + cn * Cp + kc, Cp, 1, NB, true};         // T[k][n] read from T^T[n][k]
+  const int sm = blockIdx.z >> 1, sn = blockIdx.z & 1;
+  const long rm = (long)(cb0 + ti) * NB + 64 * sm, cn = (long)(a0 + tj) * NB + 64 * sn, kc = (long)cb0 * NB;
+  Operand<float> a{Linv + rm * Cp + kc, Cp, 1, 64, true};         // Cinv[m][k], lower: k <= m
+  Operand<float> b{Linv + cn * Cp + kc, Cp, 1, 64, true};         // T[k][n] read from T^T[n][k]
   float* X = Linv + rm * Cp + cn;
-  gemm_tile<float, float, true, true>(a, b, 0, (ti + 1) * NB, smem,
-                                      Epilogue{X, Cp, 1, EPI_STORE_NEG, TRI_ALL, 0.f, 0.f});
+  gemm_tile64<float, float, true, true>(a, b, 0, ti * NB + 64 * (sm + 1), smem,
+                                        Epilogue{X, Cp, 1, EPI_STORE_NEG, TRI_ALL, 0.f, 0.f});
 }
 
 // U[i][j] = Linv[C-1-i][C-1-j] for j >= i, zero below the diagonal.
@@ -410,7 +418,7 @@ extern "C" int gptq_hinv_upper(float* H, int ldh, int C, float percdamp, const i
       if (nrem <= 0) break;
       panel_kernel<<<nrem, GEMM_THREADS, 0, s>>>(A, Linv, Cp, kb);
       if (kb + 1 < p1)                                             // the rest of this outer panel: rank-128
-        syrk_kernel<<<syrk_tiles(nblk, kb + 1, p1), GEMM_THREADS, 0, s>>>(A, Cp, nblk, kb * NB, NB, kb + 1, p1);
+        syrk_kernel<<<dim3(syrk_tiles(nblk, kb + 1, p1), 4), GEMM_THREADS, 0, s>>>(A, Cp, nblk, kb * NB, NB, kb + 1, p1);
     }
     if (p1 < nblk) {                                               // everything beyond: rank-((p1 - p0) * 128)
       if (side_busy) {                                             // the previous far update wrote these tiles too
@@ -418,7 +426,7 @@ extern "C" int gptq_hinv_upper(float* H, int ldh, int C, float percdamp, const i
         side_busy = false;
       }
       const int q1 = std::min(p1 + CSUPER, nblk);
-      syrk_kernel<<<syrk_tiles(nblk, p1, q1), GEMM_THREADS, 0, s>>>(A, Cp, nblk, p0 * NB, (p1 - p0) * NB, p1, q1);
+      syrk_kernel<<<dim3(syrk_tiles(nblk, p1, q1), 4), GEMM_THREADS, 0, s>>>(A, Cp, nblk, p0 * NB, (p1 - p0) * NB, p1, q1);
       if (q1 < nblk) {
         hipStream_t ts = s;
         if (sc) {
@@ -426,7 +434,7 @@ extern "C" int gptq_hinv_upper(float* H, int ldh, int C, float percdamp, const i
           GPTQ_CHECK_HIP(hipStreamWaitEvent(sc->stream, sc->main_done, 0));
           ts = sc->stream;
         }
-        syrk_kernel<<<syrk_tiles(nblk, q1, nblk), GEMM_THREADS, 0, ts>>>(A, Cp, nblk, p0 * NB, (p1 - p0) * NB, q1, nblk);
+        syrk_kernel<<<dim3(syrk_tiles(nblk, q1, nblk), 4), GEMM_THREADS, 0, ts>>>(A, Cp, nblk, p0 * NB, (p1 - p0) * NB, q1, nblk);
         if (sc) {
           GPTQ_CHECK_HIP(hipEventRecord(sc->side_done, sc->stream));
           side_busy = true;
@@ -437,8 +445,8 @@ extern "C" int gptq_hinv_upper(float* H, int ldh, int C, float percdamp, const i
   if (side_busy) GPTQ_CHECK_HIP(hipStreamWaitEvent(s, sc->side_done, 0));
   for (int sz = 1; sz < nblk; sz *= 2) {
     const int pairs = cdiv(nblk, 2 * sz);
-    trtri_step1_kernel<<<dim3(sz * sz, pairs), GEMM_THREADS, 0, s>>>(A, Linv, Cp, nblk, sz, 0);
-    trtri_step2_kernel<<<dim3(sz * sz, pairs), GEMM_THREADS, 0, s>>>(Linv, Cp, nblk, sz, 0);
+    trtri_step1_kernel<<<dim3(sz * sz, pairs, 4), GEMM_THREADS, 0, s>>>(A, Linv, Cp, nblk, sz, 0);
+    trtri_step2_kernel<<<dim3(sz * sz, pairs, 4), GEMM_THREADS, 0, s>>>(Linv, Cp, nblk, sz, 0);
   }
   flip_to_upper_kernel<<<dim3(cdiv(C, 256), C), 256, 0, s>>>(Linv, Cp, C, H, ldh);
   GPTQ_CHECK_LAUNCH("gptq_hinv_upper");

@@ -45,6 +45,7 @@ struct SideCtx {
   hipStream_t stream = nullptr;
   hipEvent_t main_done = nullptr;   // recorded on the caller's stream
   hipEvent_t side_done = nullptr;   // recorded on the side stream
+  hipEvent_t prep_done = nullptr;   // recorded on the side stream: input preparation that runs beside the factorization
 };
 SideCtx* side_ctx(hipStream_t main);   // nullptr if it cannot be created (callers then run serially)
 // Library-owned device scratch per (device, caller stream), grown on demand and kept (nullptr on failure).

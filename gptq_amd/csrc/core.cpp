@@ -30,6 +30,7 @@ SideCtx* side_ctx(hipStream_t main) {
   if (hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
   if (hipEventCreateWithFlags(&c.main_done, hipEventDisableTiming) != hipSuccess) return nullptr;
   if (hipEventCreateWithFlags(&c.side_done, hipEventDisableTiming) != hipSuccess) return nullptr;
+  if (hipEventCreateWithFlags(&c.prep_done, hipEventDisableTiming) != hipSuccess) return nullptr;
   return &table.emplace(key, c).first->second;
 }
 

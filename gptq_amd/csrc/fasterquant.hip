@@ -8,7 +8,7 @@
 // tolerance-level: their summation order differs from MKL's.
 #include <algorithm>
 
-#include "gemm_f32.h"
+#include "gemm2_f32.h"
 
 namespace gptq {
 
@@ -63,6 +63,40 @@ __global__ void permute_cols_kernel(const T* __restrict__ src, int lds_, T* __re
   const long r = blockIdx.y;
   if (SCATTER) dst[r * ldd + perm[p]] = src[r * lds_ + p];
   else dst[r * ldd + p] = src[r * lds_ + perm[p]];
+}
+
+// The same through LDS, one workgroup per row at a time: the row is read and written with coalesced 16-byte accesses and
+// the permutation happens inside LDS (the direct kernel above moves 4 bytes per 64-byte sector on its permuted side).
+// C * 4 bytes of dynamic LDS (C <= 36864); C % 4 == 0 and 16-byte aligned rows.
+template <bool SCATTER>
+__global__ __launch_bounds__(512) void permute_rows_lds_kernel(const float* __restrict__ src, int lds_, float* __restrict__ dst,
+                                                               int ldd, int R, int C, const int32_t* __restrict__ perm) {
+  extern __shared__ __attribute__((aligned(16))) float rowbuf[];
+  for (int r = blockIdx.x; r < R; r += gridDim.x) {
+    const float* s = src + (long)r * lds_;
+    float* d = dst + (long)r * ldd;
+    if (SCATTER) {
+      for (int p = threadIdx.x * 4; p < C; p += 2048) {
+        const float4 v = *reinterpret_cast<const float4*>(s + p);
+        const int4 q = *reinterpret_cast<const int4*>(perm + p);
+        rowbuf[q.x] = v.x; rowbuf[q.y] = v.y; rowbuf[q.z] = v.z; rowbuf[q.w] = v.w;
+      }
+    } else {
+      for (int p = threadIdx.x * 4; p < C; p += 2048)
+        *reinterpret_cast<float4*>(rowbuf + p) = *reinterpret_cast<const float4*>(s + p);
+    }
+    __syncthreads();
+    if (SCATTER) {
+      for (int p = threadIdx.x * 4; p < C; p += 2048)
+        *reinterpret_cast<float4*>(d + p) = *reinterpret_cast<const float4*>(rowbuf + p);
+    } else {
+      for (int p = threadIdx.x * 4; p < C; p += 2048) {
+        const int4 q = *reinterpret_cast<const int4*>(perm + p);
+        *reinterpret_cast<float4*>(d + p) = make_float4(rowbuf[q.x], rowbuf[q.y], rowbuf[q.z], rowbuf[q.w]);
+      }
+    }
+    __syncthreads();
+  }
 }
 
 // col_group[p] = (perm ? perm[p] : p) / groupsize   (gptq.py:256-260)
@@ -350,18 +384,38 @@ __global__ __launch_bounds__(GEMM_THREADS) void trailing_kernel(float* __restric
                                                                 int c_end, const float* __restrict__ E, int lde,
                                                                 int K, const float* __restrict__ U, int ldu, int u0,
                                                                 bool bvec) {
-  __shared__ __attribute__((aligned(16))) float smem[GEMM_LDS_FLOATS];
+  // 64 x 64 output tiles (gemm2_f32.h): 2x faster than 128 x 128 ones on the small launches inside a super-block,
+  // never slower on the large ones, bit-identical
+  __shared__ __attribute__((aligned(16))) float smem[GEMM64_LDS_FLOATS];
   const int tn = blockIdx.x, tm = blockIdx.y;
-  const long r0 = (long)tm * GBM, c0 = (long)c_begin + (long)tn * GBN;
-  Operand<float> a{E + r0 * lde, lde, 1, (int)min((long)GBM, R - r0), (lde % 4) == 0};
-  Operand<float> b{U + (long)u0 * ldu + c0, 1, ldu, (int)min((long)GBN, c_end - c0), bvec};
+  const long r0 = (long)tm * SBM, c0 = (long)c_begin + (long)tn * SBN;
+  Operand<float> a{E + r0 * lde, lde, 1, (int)min((long)SBM, R - r0), (lde % 4) == 0};
+  Operand<float> b{U + (long)u0 * ldu + c0, 1, ldu, (int)min((long)SBN, c_end - c0), bvec};
   float* Wt = W + r0 * ldw + c0;
-  gemm_tile<float, float, true, false>(a, b, 0, K, smem, Epilogue{Wt, ldw, 1, EPI_SUB, TRI_ALL, 0.f, 0.f});
+  gemm_tile64<float, float, true, false>(a, b, 0, K, smem, Epilogue{Wt, ldw, 1, EPI_SUB, TRI_ALL, 0.f, 0.f});
 }
 
 }  // namespace gptq
 
 using namespace gptq;
+
+// W columns through the act-order permutation (gather: gptq.py:167, scatter back: gptq.py:301)
+template <bool SCATTER>
+static int permute_cols(const float* src, int lds_, float* dst, int ldd, int R, int C, const int32_t* perm, hipStream_t s) {
+  const bool fast = C % 4 == 0 && C <= 36864 && lds_ % 4 == 0 && ldd % 4 == 0 &&
+                    reinterpret_cast<uintptr_t>(src) % 16 == 0 && reinterpret_cast<uintptr_t>(dst) % 16 == 0 &&
+                    reinterpret_cast<uintptr_t>(perm) % 16 == 0;
+  if (fast) {
+    const size_t bytes = sizeof(float) * (size_t)C;
+    GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&permute_rows_lds_kernel<SCATTER>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    permute_rows_lds_kernel<SCATTER><<<std::min(R, 1024), 512, bytes, s>>>(src, lds_, dst, ldd, R, C, perm);
+  } else {
+    permute_cols_kernel<float, SCATTER><<<dim3(cdiv(C, 256), R), 256, 0, s>>>(src, lds_, dst, ldd, C, perm);
+  }
+  GPTQ_CHECK_LAUNCH("permute_cols");
+  return GPTQ_OK;
+}
 
 // =============================================================================================
 // C ABI
@@ -502,40 +556,52 @@ extern "C" int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R
 
   // dead columns (gptq.py:143-145)
   dead_fix_kernel<<<cdiv(C, TB), TB, 0, s>>>(H, ldh, C, ws.dead, ws.diag);
-  zero_dead_kernel<<<dim3(cdiv(C, TB), R), TB, 0, s>>>(W, ldw, R, C, ws.dead);
-
+  if (actorder) argsort_desc_kernel<<<cdiv(C, 256), 256, 0, s>>>(ws.diag, C, ws.perm);   // gptq.py:166
+  // Everything that prepares W (dead columns zeroed, static-group grids, act-order gather, full-row grid) depends on
+  // diag(H) only, not on the factorization: it runs on the helper stream beside the chain below, which is serial and
+  // latency-bound and leaves the chip idle.  (No helper stream: same kernels, caller's stream.)
+  SideCtx* sc = (lookahead_mask() & 2) ? side_ctx(s) : nullptr;
+  hipStream_t ps = s;
+  if (sc) {
+    GPTQ_CHECK_HIP(hipEventRecord(sc->main_done, s));
+    GPTQ_CHECK_HIP(hipStreamWaitEvent(sc->stream, sc->main_done, 0));
+    ps = sc->stream;
+  }
+  zero_dead_kernel<<<dim3(cdiv(C, TB), R), TB, 0, ps>>>(W, ldw, R, C, ws.dead);
   // static groups: grids of the ORIGINAL, uncompensated columns (gptq.py:157-163)
   if (use_static)
-    find_params_kernel<<<dim3(cdiv(R, 4), G), 256, 0, s>>>(W, ldw, R, 0, C, groupsize, maxq, sym,
-                                                           ws.stab, ws.ztab, G, 0);
+    find_params_kernel<<<dim3(cdiv(R, 4), G), 256, 0, ps>>>(W, ldw, R, 0, C, groupsize, maxq, sym,
+                                                            ws.stab, ws.ztab, G, 0);
   // act-order (gptq.py:165-169)
   float* Wk = W;
   int ldk = ldw;
   const int32_t* perm = nullptr;
   if (actorder) {
-    argsort_desc_kernel<<<cdiv(C, 256), 256, 0, s>>>(ws.diag, C, ws.perm);
-    permute_cols_kernel<float, false><<<dim3(cdiv(C, TB), R), TB, 0, s>>>(W, ldw, ws.Wp, C, C, ws.perm);
+    if (int rc = permute_cols<false>(W, ldw, ws.Wp, C, R, C, ws.perm, ps)) return rc;
     Wk = ws.Wp;
     ldk = C;
     perm = ws.perm;
-    if (perm_out) GPTQ_CHECK_HIP(hipMemcpyAsync(perm_out, ws.perm, sizeof(int32_t) * C, hipMemcpyDeviceToDevice, s));
+    if (perm_out) GPTQ_CHECK_HIP(hipMemcpyAsync(perm_out, ws.perm, sizeof(int32_t) * C, hipMemcpyDeviceToDevice, ps));
   }
+  // full-row grid unless the quantizer is ready (gptq.py:181-185; per-row min / max do not depend on the column order
+  // nor on the factorization, so this may precede it)
+  if (!grouped) {
+    if (preset) {
+      GPTQ_CHECK_HIP(hipMemcpyAsync(ws.stab, scale_io, sizeof(float) * R, hipMemcpyDeviceToDevice, ps));
+      GPTQ_CHECK_HIP(hipMemcpyAsync(ws.ztab, zero_io, sizeof(float) * R, hipMemcpyDeviceToDevice, ps));
+    } else {
+      find_params_kernel<<<dim3(cdiv(R, 4), 1), 256, 0, ps>>>(Wk, ldk, R, 0, C, C, maxq, sym, ws.stab, ws.ztab, 1, 0);
+    }
+  } else {
+    col_group_kernel<<<cdiv(C, TB), TB, 0, ps>>>(ws.cgroup, C, use_static ? perm : nullptr, groupsize);
+  }
+  if (sc) GPTQ_CHECK_HIP(hipEventRecord(sc->prep_done, sc->stream));
   // damped inverse factor (gptq.py:174-180): H <- U
   {
     const int rc = gptq_hinv_upper(H, ldh, C, percdamp, perm, info, ws.hinv, ws.hinv_bytes, stream);
     if (rc != GPTQ_OK) return rc;
   }
-  // full-row grid unless the quantizer is ready (gptq.py:181-185)
-  if (!grouped) {
-    if (preset) {
-      GPTQ_CHECK_HIP(hipMemcpyAsync(ws.stab, scale_io, sizeof(float) * R, hipMemcpyDeviceToDevice, s));
-      GPTQ_CHECK_HIP(hipMemcpyAsync(ws.ztab, zero_io, sizeof(float) * R, hipMemcpyDeviceToDevice, s));
-    } else {
-      find_params_kernel<<<dim3(cdiv(R, 4), 1), 256, 0, s>>>(Wk, ldk, R, 0, C, C, maxq, sym, ws.stab, ws.ztab, 1, 0);
-    }
-  } else {
-    col_group_kernel<<<cdiv(C, TB), TB, 0, s>>>(ws.cgroup, C, use_static ? perm : nullptr, groupsize);
-  }
+  if (sc) GPTQ_CHECK_HIP(hipStreamWaitEvent(s, sc->prep_done, 0));
   GPTQ_CHECK_HIP(hipMemsetAsync(ws.loss, 0, sizeof(float) * R, s));
 
   const bool bvec_base = (ldh % 4 == 0) && (reinterpret_cast<uintptr_t>(H) % 16 == 0);
@@ -545,7 +611,6 @@ extern "C" int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R
   const int SB = hier ? SUPER * blocksize : blocksize;
   // Look-ahead: the far update of a super-block is split into "the next super-block's columns" (caller's stream: the
   // column loop needs them next) and "everything beyond" (helper stream, underneath the next super-block's loop).
-  SideCtx* sc = (lookahead_mask() & 2) ? side_ctx(s) : nullptr;
   bool side_busy = false;
   int sblk = 0;
   for (int s0 = 0; s0 < C; s0 += SB, ++sblk) {
@@ -574,7 +639,7 @@ extern "C" int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R
       const int rc = launch_quant_block(a, blocksize, grouped, s);
       if (rc != GPTQ_OK) return rc;
       if (i2 < s1)                                                   // the rest of this super-block: rank-blocksize
-        trailing_kernel<<<dim3(cdiv(s1 - i2, GBN), cdiv(R, GBM)), GEMM_THREADS, 0, s>>>(
+        trailing_kernel<<<dim3(cdiv(s1 - i2, SBN), cdiv(R, SBM)), GEMM_THREADS, 0, s>>>(
             Wk, ldk, R, i2, s1, Err, SB, count, H, ldh, i1, bvec_base && (i2 % 4 == 0));
     }
     if (s1 < C) {                                                    // everything beyond: rank-(s1 - s0)
@@ -584,7 +649,7 @@ extern "C" int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R
       }
       const bool bvec = bvec_base && (s1 % 4 == 0);
       const int next_end = std::min(C, s1 + SB);
-      trailing_kernel<<<dim3(cdiv(next_end - s1, GBN), cdiv(R, GBM)), GEMM_THREADS, 0, s>>>(
+      trailing_kernel<<<dim3(cdiv(next_end - s1, SBN), cdiv(R, SBM)), GEMM_THREADS, 0, s>>>(
           Wk, ldk, R, s1, next_end, ErrS, SB, s1 - s0, H, ldh, s0, bvec);
       if (next_end < C) {
         hipStream_t ts = s;
@@ -593,7 +658,7 @@ extern "C" int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R
           GPTQ_CHECK_HIP(hipStreamWaitEvent(sc->stream, sc->main_done, 0));
           ts = sc->stream;
         }
-        trailing_kernel<<<dim3(cdiv(C - next_end, GBN), cdiv(R, GBM)), GEMM_THREADS, 0, ts>>>(
+        trailing_kernel<<<dim3(cdiv(C - next_end, SBN), cdiv(R, SBM)), GEMM_THREADS, 0, ts>>>(
             Wk, ldk, R, next_end, C, ErrS, SB, s1 - s0, H, ldh, s0, bvec_base && (next_end % 4 == 0));
         if (sc) {
           GPTQ_CHECK_HIP(hipEventRecord(sc->side_done, sc->stream));
@@ -604,7 +669,7 @@ extern "C" int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R
   }
   if (side_busy) GPTQ_CHECK_HIP(hipStreamWaitEvent(s, sc->side_done, 0));
   if (actorder)                                                  // gptq.py:300-301
-    permute_cols_kernel<float, true><<<dim3(cdiv(C, TB), R), TB, 0, s>>>(ws.Wp, C, W, ldw, C, ws.perm);
+    if (int rc = permute_cols<true>(ws.Wp, C, W, ldw, R, C, ws.perm, s)) return rc;
 
   // grid left in the quantizer + optional tables + sum(Losses) (gptq.py:294)
   gather_tab_col_kernel<<<cdiv(R, TB), TB, 0, s>>>(ws.stab, ws.ztab, G, grouped ? ws.cgroup : nullptr,

@@ -1,8 +1,150 @@
-// placeholder: second-generation fp32 MFMA GEMM variants under evaluation (tools/microbench/gemm_f32_bench.hip)
+// Small-tile companion of gemm_f32.h: the same exact-fp32 MFMA product on a 64x64 output tile per 256-thread workgroup
+// (each wave owns ONE 32x32 accumulator).  For the latency-bound launches of the solve -- the panel solve, the rank-128
+// updates inside a super-block / outer panel -- which bring a few dozen 128x128 tiles: four times the workgroups, a
+// quarter of the MFMA time per workgroup, the same operand traffic per flop from L2.
 #pragma once
 #include "gemm_f32.h"
+
 namespace gptq {
-constexpr int GEMM2_VARIANTS = 0;
-inline const char* gemm2_name(int) { return ""; }
-inline void gemm2_launch(int, float*, int, const float*, int, const float*, int, int, int, int, bool, int, hipStream_t) {}
+
+constexpr int SBM = 64;
+constexpr int SBN = 64;
+constexpr int SGST = GBK / 16;                       // 4-element pieces per thread per operand stage (64 x 32 floats)
+constexpr int GEMM64_LDS_FLOATS = 2 * 2 * GBK * 68;  // A, B x double buffer, [k][64 + 4]
+
+template <typename T, bool KC>
+__device__ __forceinline__ void stage_load64(const Operand<T>& o, int k0, int k_end, float r[SGST][4]) {
+  const int tid = threadIdx.x;
+  if (!KC) {                                         // thread -> (k = tid >> 4 [+16h], 4 consecutive tile rows)
+    const int m4 = (tid & 15) * 4;
+#pragma unroll
+    for (int h = 0; h < SGST; ++h) {
+      const int k = k0 + (tid >> 4) + 16 * h;
+      const T* p = o.p + (long)m4 * o.st + (long)k * o.sk;
+      if (k < k_end && o.vec && m4 + 4 <= o.rem) {
+        load4_vec<T>(p, r[h]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[h][e] = (k < k_end && m4 + e < o.rem) ? to_f32<T>(p[(long)e * o.st]) : 0.f;
+      }
+    }
+  } else {                                           // thread -> (tile row = tid >> 3 [+32h], 4 consecutive k)
+    const int k = k0 + (tid & 7) * 4;
+#pragma unroll
+    for (int h = 0; h < SGST; ++h) {
+      const int m = (tid >> 3) + 32 * h;
+      const T* p = o.p + (long)m * o.st + (long)k * o.sk;
+      if (m < o.rem && o.vec && k + 4 <= k_end) {
+        load4_vec<T>(p, r[h]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[h][e] = (m < o.rem && k + e < k_end) ? to_f32<T>(p[(long)e * o.sk]) : 0.f;
+      }
+    }
+  }
+}
+
+template <bool KC>
+struct LdsStride64 { static constexpr int v = KC ? 65 : 68; };
+
+template <bool KC>
+__device__ __forceinline__ void stage_store64(float* S, const float r[SGST][4]) {
+  constexpr int LDS_ = LdsStride64<KC>::v;
+  const int tid = threadIdx.x;
+  if (!KC) {
+    const int m4 = (tid & 15) * 4;
+#pragma unroll
+    for (int h = 0; h < SGST; ++h) {
+      const int k = (tid >> 4) + 16 * h;
+      *reinterpret_cast<float4*>(S + k * LDS_ + m4) = make_float4(r[h][0], r[h][1], r[h][2], r[h][3]);
+    }
+  } else {
+    const int k = (tid & 7) * 4;
+#pragma unroll
+    for (int h = 0; h < SGST; ++h) {
+      const int m = (tid >> 3) + 32 * h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) S[(k + e) * LDS_ + m] = r[h][e];
+    }
+  }
+}
+
+__device__ __forceinline__ void tile_epilogue64(const f32x16& acc, const Epilogue& ep, int rem_m, int rem_n, int wm,
+                                                int wn, int lane) {
+  const bool rmw = ep.mode == EPI_SUB || ep.mode == EPI_AXPBY;
+  float old[16];
+  if (rmw) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+      const int col = wn * 32 + (lane & 31);
+      old[e] = (row < rem_m && col < rem_n) ? ep.C[(long)row * ep.rs + (long)col * ep.cs] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int row = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+    const int col = wn * 32 + (lane & 31);
+    bool keep = row < rem_m && col < rem_n;
+    if (ep.tri == TRI_LOWER) keep = keep && row >= col;
+    if (ep.tri == TRI_UPPER) keep = keep && row <= col;
+    const float v = acc[e];
+    float out;
+    if (ep.mode == EPI_STORE) out = v;
+    else if (ep.mode == EPI_STORE_NEG) out = -v;
+    else if (ep.mode == EPI_SUB) out = old[e] - v;
+    else out = ep.alpha * old[e] + ep.beta * v;
+    if (keep) ep.C[(long)row * ep.rs + (long)col * ep.cs] = out;
+  }
+}
+
+// C_tile(64 x 64) = sum_{k in [k_begin, k_end)} A(m,k) * B(n,k), combined with memory as `ep` says.  The k order of
+// every output element is the same ascending fmaf chain as gemm_tile's: bit-identical results.
+// `smem` must hold GEMM64_LDS_FLOATS floats.
+template <typename TA, typename TB, bool AKC, bool BKC>
+__device__ __forceinline__ void gemm_tile64(const Operand<TA>& a, const Operand<TB>& b, int k_begin, int k_end,
+                                            float* smem, const Epilogue& ep) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  float* As = smem;
+  float* Bs = smem + 2 * GBK * 68;
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  float ra[SGST][4], rb[SGST][4];
+  const int nk = (k_end - k_begin + GBK - 1) / GBK;
+  if (nk > 0) {
+    stage_load64<TA, AKC>(a, k_begin, k_end, ra);
+    stage_load64<TB, BKC>(b, k_begin, k_end, rb);
+    stage_store64<AKC>(As, ra);
+    stage_store64<BKC>(Bs, rb);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) {
+      stage_load64<TA, AKC>(a, k_begin + (kt + 1) * GBK, k_end, ra);
+      stage_load64<TB, BKC>(b, k_begin + (kt + 1) * GBK, k_end, rb);
+    }
+    constexpr int LDA = LdsStride64<AKC>::v, LDB = LdsStride64<BKC>::v;
+    const float* Ac = As + cur * GBK * 68 + wm * 32 + (lane & 31);
+    const float* Bc = Bs + cur * GBK * 68 + wn * 32 + (lane & 31);
+#pragma unroll
+    for (int kk = 0; kk < GBK; kk += 2) {
+      const int k = kk + (lane >> 5);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[k * LDA], Bc[k * LDB], acc, 0, 0, 0);
+    }
+    if (more) {
+      stage_store64<AKC>(As + (cur ^ 1) * GBK * 68, ra);
+      stage_store64<BKC>(Bs + (cur ^ 1) * GBK * 68, rb);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  tile_epilogue64(acc, ep, a.rem, b.rem, wm, wn, lane);
+}
+
 }  // namespace gptq

@@ -11,7 +11,7 @@
 #include <cmath>
 
 #include "../../gptq_amd/csrc/gemm_f32.h"
-#include "../../gptq_amd/csrc/gemm2_f32.h"
+#include "gemm_variants.h"
 
 namespace gptq { void set_error(const char*, ...) {} }
 using namespace gptq;
@@ -38,6 +38,15 @@ static void fill(std::vector<float>& v, unsigned seed) {
 int main(int argc, char** argv) {
   struct Shape { int M, N, K; bool nt; int mode; const char* what; };
   std::vector<Shape> shapes = {
+      {4096, 128, 128, false, EPI_SUB, "near-next R=4096 (32 tiles)"},
+      {4096, 384, 128, false, EPI_SUB, "near R=4096 N=384"},
+      {12288, 256, 128, false, EPI_SUB, "near R=12288 N=256"},
+      {22016, 256, 128, false, EPI_SUB, "near R=22016 N=256"},
+      {4096, 512, 512, false, EPI_SUB, "far-next R=4096 (K=512,N=512)"},
+      {3968, 128, 128, true, EPI_STORE, "panel 31 tiles (nt, store)"},
+      {10880, 128, 128, true, EPI_STORE, "panel 85 tiles (nt, store)"},
+      {3968, 384, 128, true, EPI_SUB, "near-syrk 31x3 tiles"},
+      {10880, 384, 128, true, EPI_SUB, "near-syrk 85x3 tiles"},
       {12288, 3584, 128, false, EPI_SUB, "trailing qkv (rank-128, nn, RMW)"},
       {22016, 2048, 128, false, EPI_SUB, "trailing gate/up (rank-128, nn, RMW)"},
       {4096, 8192, 128, false, EPI_SUB, "trailing down (rank-128, nn, RMW)"},
