@@ -58,21 +58,6 @@ __global__ __launch_bounds__(256) void build_abar_kernel(const float* __restrict
   A[(long)i * Cp + j] = v;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Diagonal block: L_kk = chol(A_kk) and X = L_kk^-1 (written to the diagonal block of Linv); hierarchical,
-// 32-wide sub-blocks.
-//   factorization, for s = 0..3:  (A1) wave 0 factors the 32x32 diagonal sub-block in REGISTERS (lane =
-//   row, v_readlane broadcasts, no barrier inside);  (A2) the sub-panel below is solved by per-row forward
-//   substitution (thread = row, L_D broadcast from LDS);  (A3) the remaining sub-blocks get their rank-32
-//   update on the matrix cores (one 32x32 tile per wave).  3 barriers per 32 columns instead of 1 per column.
-//   inverse:  (B1) the four 32x32 diagonal inverses by column-per-lane substitution (4 waves in
-//   parallel);  (B2/B3) two levels of recursive doubling on the matrix cores, the intermediate product of
-//   level 1 staying in accumulator registers (it is consumed as the next MFMA's B operand directly).
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float lane_bcast(float v, int l) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-}
-
 // acc(32x32, MFMA C layout) += sign * A * B  over K = 32, operands addressed as A(i,k) = Ap[i*lda + k],
 // B(k,j) = Bp[j*ldb + k]  (i.e. B given as its transpose, row-major), all in LDS.
 __device__ __forceinline__ void lds_mfma32(f32x16& acc, const float* Ap, int lda, const float* Bp, int ldb,
@@ -105,16 +90,47 @@ __device__ __forceinline__ void acc_store(const f32x16& acc, float* T, int ld, i
   for (int e = 0; e < 16; ++e) T[((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * ld + (lane & 31)] = acc[e];
 }
 
-__global__ __launch_bounds__(512) void potrf_inv_diag_v2_kernel(float* __restrict__ A, float* __restrict__ Linv,
-                                                                int Cp, int kb, int32_t* __restrict__ info, int ablate) {
+// ---------------------------------------------------------------------------------------------
+// Diagonal block: L_kk = chol(A_kk), X = L_kk^-1 written to the diagonal block of Linv.  Hierarchical on 32-wide
+// sub-blocks; the 32 x 32 diagonal sub-blocks are factorized AND inverted on the matrix
+// cores, one rank-1 update per column.  The sub-block D sits in ONE wave as a 32x32 MFMA accumulator (C layout:
+// lane = column, register = row group).  D is symmetric, so its row j -- register e_j of the 32 lanes of half h_j -- is
+// also its column j, already spread one element per lane exactly where `v_mfma_f32_32x32x2_f32` takes its A and B
+// operands of k-slot h_j: no broadcast, no transposition, the rank-1 update D -= l l^T is ONE MFMA with the scaled row
+// in both operand registers (the other half of the wave supplies zeros).  The inverse rides along: M starts as I, per
+// column x_j = M[j, :] / l_jj is row j of D^-1 and M -= l_(i>j) x_j is a second MFMA (forward substitution of all 32
+// unit vectors at once).  Per column: readlane (pivot) -> rsq + Newton -> two selects -> two MFMAs; the 32-column
+// chain takes ~2.5 us instead of ~7 us with v_readlane broadcasts of every multiplier (+ ~1.5 us for the inverse).
+// The sub-panel below D is then a plain product with D^-1 (MFMA) instead of a per-row substitution.
+// ---------------------------------------------------------------------------------------------
+template <int J>
+__device__ __forceinline__ void factor32_step(f32x16& S, f32x16& M, float* Xd, int ldx, int32_t* info, int col0,
+                                              int lane) {
+  constexpr int e = (J & 3) + 4 * (J >> 3);       // register holding row J
+  constexpr int h = (J >> 2) & 1;                 // half of the wave holding row J
+  const int c = lane & 31;
+  const float srow = S[e];                        // (a copy: __builtin_bit_cast of a vector ELEMENT reads element 0)
+  const float ajj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, srow), J + 32 * h));
+  // 1/sqrt by v_rsq_f32 + one Newton step, l_jj = a_jj * that (tolerance-level, like the rest of the chain)
+  float inv = __builtin_amdgcn_rsqf(ajj);
+  inv = inv * (1.5f - 0.5f * ajj * inv * inv);
+  if (!(ajj > 0.f) && lane == 0 && info) atomicCAS(info, 0, col0 + J + 1);
+  const bool mine = (lane >> 5) == h;
+  const float l = (mine && c >= J) ? srow * inv : 0.f;          // column J of L_D, l_J = sqrt(a_JJ)
+  const float x = mine ? M[e] * inv : 0.f;                      // row J of L_D^-1 (exact zeros right of the diagonal)
+  if (mine) Xd[J * ldx + c] = x;
+  const float ls = (c > J) ? l : 0.f;
+  S = __builtin_amdgcn_mfma_f32_32x32x2f32(-l, l, S, 0, 0, 0);
+  M = __builtin_amdgcn_mfma_f32_32x32x2f32(-ls, x, M, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__ A, float* __restrict__ Linv,
+                                                                int Cp, int kb, int32_t* __restrict__ info) {
   constexpr int LD = NB + 1;            // 129: row-strided accesses (lane = row) are conflict-free
-  constexpr int LDD = 36;               // 32x32 scratch blocks, 16-byte aligned rows
   extern __shared__ __attribute__((aligned(16))) float dsm[];
-  float* S = dsm;                       // [128][129]  A_kk -> L_kk (lower)
+  float* S = dsm;                       // [128][129]  A_kk (full, mirrored) -> L off-diagonal blocks
   float* Xs = S + NB * LD;              // [128][129]  L_kk^-1 (lower, zero above)
-  float* Ld = Xs + NB * LD;             // [32][36]    current diagonal sub-block L_D (row-major)
-  float* Tt = Ld + 32 * LDD;            // [64][65]    level-2 intermediate T = L_CA * X_A
-  float* rd = Tt + 64 * 65;             // [128]       1 / l_jj
+  float* Tt = Xs + NB * LD;             // [64][65]    level-2 intermediate T = L_CA * X_A
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* Ak = A + (long)kb * NB * Cp + (long)kb * NB;
@@ -125,70 +141,44 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_v2_kernel(float* __restric
     Xs[i * LD + k] = 0.f;
   }
   __syncthreads();
-  for (int idx = tid; idx < NB * NB; idx += 512) {              // mirror inside LDS (A3 updates full diagonal tiles)
+  for (int idx = tid; idx < NB * NB; idx += 512) {              // mirror inside LDS (diagonal tiles are kept full)
     const int i = idx >> 7, k = idx & 127;
     if (k > i) S[i * LD + k] = S[k * LD + i];
   }
   __syncthreads();
-  const int abl = ablate;   // diagnostic: bit 0 skip A1, bit 1 skip A2, bit 2 skip A3, bit 3 skip inverse
 
   // ------------------------------- factorization -------------------------------
 #pragma unroll 1
   for (int s = 0; s < 4; ++s) {
     const int o = 32 * s;
-    if (wave == 0 && !(abl & 1)) {                              // (A1) 32x32 in registers, lane = row
-      const int row = lane & 31;
-      float a[32];
+    if (wave == 0) {                                            // (A1) D = L_D L_D^T and X_D = L_D^-1 on the matrix cores
+      f32x16 D, M;
+      acc_load(D, S + o * LD + o, LD, lane);
 #pragma unroll
-      for (int k = 0; k < 32; ++k) a[k] = S[(o + row) * LD + o + k];
-#pragma unroll
-      for (int j = 0; j < 32; ++j) {
-        const float ajj = lane_bcast(a[j], j);
-        // 1/sqrt by v_rsq_f32 + one Newton step, l_jj = a_jj * that: the IEEE sqrt + division pair costs ~160 more
-        // cycles on this 128-step serial chain; the factor stays within ~1 ulp (tolerance-level, like the rest)
-        float inv = __builtin_amdgcn_rsqf(ajj);
-        inv = inv * (1.5f - 0.5f * ajj * inv * inv);
-        const float d = ajj * inv;
-        if (lane == 0) {
-          rd[o + j] = inv;
-          if (!(ajj > 0.f) && info) atomicCAS(info, 0, kb * NB + o + j + 1);
-        }
-        const float lj = (row == j) ? d : a[j] * inv;
-        a[j] = lj;
-#pragma unroll
-        for (int k = j + 1; k < 32; ++k) a[k] -= lj * lane_bcast(lj, k);
-      }
-      if (lane < 32) {
-#pragma unroll
-        for (int k = 0; k < 32; ++k) {
-          const float v = (k <= row) ? a[k] : 0.f;
-          S[(o + row) * LD + o + k] = v;
-          Ld[row * LDD + k] = v;
-        }
-      }
+      for (int e = 0; e < 16; ++e) M[e] = ((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) == (lane & 31)) ? 1.f : 0.f;
+      float* Xd = Xs + o * LD + o;
+      const int c0 = kb * NB + o;
+#define FSTEP(J) factor32_step<J>(D, M, Xd, LD, info, c0, lane)
+      FSTEP(0); FSTEP(1); FSTEP(2); FSTEP(3); FSTEP(4); FSTEP(5); FSTEP(6); FSTEP(7);
+      FSTEP(8); FSTEP(9); FSTEP(10); FSTEP(11); FSTEP(12); FSTEP(13); FSTEP(14); FSTEP(15);
+      FSTEP(16); FSTEP(17); FSTEP(18); FSTEP(19); FSTEP(20); FSTEP(21); FSTEP(22); FSTEP(23);
+      FSTEP(24); FSTEP(25); FSTEP(26); FSTEP(27); FSTEP(28); FSTEP(29); FSTEP(30); FSTEP(31);
+#undef FSTEP
     }
     __syncthreads();
-    const int below = NB - o - 32;                              // rows under the diagonal sub-block
-    if (tid < below && !(abl & 2)) {                            // (A2) x * L_D^T = p, one row per thread
-      const int i = o + 32 + tid;
-      float x[32];
+    const int nb_rem = 3 - s;                                   // 32-row blocks under the diagonal sub-block
+    if (wave < nb_rem) {                                        // (A2) P_I = A[I, s] * X_D^T, one block per wave
+      const int ri = 32 * (s + 1 + wave);
+      f32x16 acc;
 #pragma unroll
-      for (int k = 0; k < 32; ++k) x[k] = S[i * LD + o + k];
-#pragma unroll
-      for (int j = 0; j < 32; ++j) {
-        float acc = x[j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) acc -= x[k] * Ld[j * LDD + k];
-        x[j] = acc * rd[o + j];
-      }
-#pragma unroll
-      for (int k = 0; k < 32; ++k) S[i * LD + o + k] = x[k];
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+      lds_mfma32(acc, S + ri * LD + o, LD, Xs + o * LD + o, LD, 1.f, lane);
+      acc_store(acc, S + ri * LD + o, LD, lane);
     }
     __syncthreads();
     {                                                           // (A3) S[I,K] -= P_I P_K^T, s < K <= I
-      const int nb_rem = 3 - s;                                 // sub-blocks left: indices s+1 .. 3
       const int ntile = nb_rem * (nb_rem + 1) / 2;
-      if (wave < ntile && !(abl & 4)) {
+      if (wave < ntile) {
         int t = wave, K = 0;
         while (t >= nb_rem - K) { t -= nb_rem - K; ++K; }
         const int I = K + t;                                    // relative indices, I >= K
@@ -201,35 +191,14 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_v2_kernel(float* __restric
     }
     __syncthreads();
   }
-  // (L_kk is not written back: the panel solve and the triangular inverse only read its inverse from Linv)
 
   // ---------------------------------- inverse ----------------------------------
-  if (abl & 8) return;
-  if (wave < 4) {                                               // (B1) X_D = L_D^-1, lane = column
-    const int o = 32 * wave;
-    const int c = lane & 31;
-    float x[32];
-#pragma unroll
-    for (int r = 0; r < 32; ++r) {
-      float acc = (r == c) ? 1.f : 0.f;
-#pragma unroll
-      for (int k = 0; k < r; ++k) acc -= S[(o + r) * LD + o + k] * x[k];     // L[r][k]: same address for all lanes
-      x[r] = (r >= c) ? acc * rd[o + r] : 0.f;
-    }
-    if (lane < 32) {
-#pragma unroll
-      for (int r = 0; r < 32; ++r) Xs[(o + r) * LD + o + c] = x[r];
-    }
-  }
-  __syncthreads();
-  if (wave < 2) {                                               // (B2) X[2p+1, 2p] = -X_C * (L_CA * X_A), 32x32 blocks
+  if (wave < 2) {                                               // X[2p+1, 2p] = -X_C * (L_CA * X_A), 32x32 blocks
     const int a0 = 64 * wave, c0 = a0 + 32;
     f32x16 T;
 #pragma unroll
     for (int e = 0; e < 16; ++e) T[e] = 0.f;
     lds_mfma32_bn(T, S + c0 * LD + a0, LD, Xs + a0 * LD + a0, LD, 1.f, lane);   // T = L_CA * X_A
-    // X = -X_C * T with T straight from the accumulator registers: MFMA step t takes, in lane half h,
-    // the k index  r(t, h) = (t & 3) + 8 * (t >> 2) + 4 * h  -- the row of T that register t holds
     f32x16 X;
 #pragma unroll
     for (int e = 0; e < 16; ++e) X[e] = 0.f;
@@ -243,7 +212,7 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_v2_kernel(float* __restric
     acc_store(X, Xs + c0 * LD + a0, LD, lane);
   }
   __syncthreads();
-  if (wave < 4) {                                               // (B3a) T[64x64] = L[64:128, 0:64] * X[0:64, 0:64]
+  if (wave < 4) {                                               // T[64x64] = L[64:128, 0:64] * X[0:64, 0:64]
     const int I = wave >> 1, J = wave & 1;
     f32x16 T;
 #pragma unroll
@@ -254,7 +223,7 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_v2_kernel(float* __restric
     acc_store(T, Tt + (32 * I) * 65 + 32 * J, 65, lane);
   }
   __syncthreads();
-  if (wave < 4) {                                               // (B3b) X[64:128, 0:64] = -X[64:128, 64:128] * T
+  if (wave < 4) {                                               // X[64:128, 0:64] = -X[64:128, 64:128] * T
     const int I = wave >> 1, J = wave & 1;
     f32x16 X;
 #pragma unroll
@@ -271,7 +240,8 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_v2_kernel(float* __restric
     Xk[(long)i * Cp + k] = (k <= i) ? Xs[i * LD + k] : 0.f;
   }
 }
-constexpr size_t POTRF_V2_LDS = sizeof(float) * (2 * NB * (NB + 1) + 32 * 36 + 64 * 65 + NB);
+constexpr size_t POTRF_LDS = sizeof(float) * (2 * NB * (NB + 1) + 64 * 65);
+
 
 // Panel:  P <- P * inv(L_kk)^T  for the block column kb below the diagonal (rows (kb+1)*128 ...).
 __global__ __launch_bounds__(GEMM_THREADS) void panel_kernel(float* __restrict__ A,
@@ -403,17 +373,12 @@ extern "C" int gptq_hinv_upper(float* H, int ldh, int C, float percdamp, const i
   // which are serial and latency-bound).
   SideCtx* sc = (lookahead_mask() & 1) ? side_ctx(s) : nullptr;
   bool side_busy = false;
-#ifdef GPTQ_DIAG   // timing-only ablation (wrong results): diagnostic library only
-  static const int potrf_abl = [] { const char* e = getenv("GPTQ_POTRF_ABLATE"); return e ? atoi(e) : 0; }();
-#else
-  const int potrf_abl = 0;
-#endif
-  GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_inv_diag_v2_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_V2_LDS));
+  GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_inv_diag_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_LDS));
   for (int p0 = 0; p0 < nblk; p0 += CSUPER) {
     const int p1 = std::min(p0 + CSUPER, nblk);
     for (int kb = p0; kb < p1; ++kb) {
-      potrf_inv_diag_v2_kernel<<<1, 512, POTRF_V2_LDS, s>>>(A, Linv, Cp, kb, info, potrf_abl);
+      potrf_inv_diag_kernel<<<1, 512, POTRF_LDS, s>>>(A, Linv, Cp, kb, info);
       const int nrem = nblk - kb - 1;
       if (nrem <= 0) break;
       panel_kernel<<<nrem, GEMM_THREADS, 0, s>>>(A, Linv, Cp, kb);
