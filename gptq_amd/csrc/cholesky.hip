@@ -125,12 +125,14 @@ __device__ __forceinline__ void factor32_step(f32x16& S, f32x16& M, float* Xd, i
 }
 
 __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__ A, float* __restrict__ Linv,
-                                                                int Cp, int kb, int32_t* __restrict__ info) {
+                                                             int Cp, int kb, int32_t* __restrict__ info) {
+  // ONE 128 x 129 image (66 KB) serves the block, its factor and its inverse: a sub-block's inverse replaces it as
+  // soon as it is final.  The footprint matters: the kernel is a single workgroup on the critical path and must find
+  // a compute unit with that much free LDS beside the big low-priority updates of the helper stream.
   constexpr int LD = NB + 1;            // 129: row-strided accesses (lane = row) are conflict-free
   extern __shared__ __attribute__((aligned(16))) float dsm[];
-  float* S = dsm;                       // [128][129]  A_kk (full, mirrored) -> L off-diagonal blocks
-  float* Xs = S + NB * LD;              // [128][129]  L_kk^-1 (lower, zero above)
-  float* Tt = Xs + NB * LD;             // [64][65]    level-2 intermediate T = L_CA * X_A
+  float* S = dsm;                       // [128][129]  A_kk (full, mirrored) -> L off-diagonal blocks -> L_kk^-1
+  float* Tt = S + 64;                   // [64][LD]    level-2 intermediate, in the dead quadrant S[0:64, 64:128]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* Ak = A + (long)kb * NB * Cp + (long)kb * NB;
@@ -138,7 +140,6 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
   for (int idx = tid; idx < NB * NB; idx += 512) {              // coalesced: lower triangle only
     const int i = idx >> 7, k = idx & 127;
     if (k <= i) S[i * LD + k] = Ak[(long)i * Cp + k];
-    Xs[i * LD + k] = 0.f;
   }
   __syncthreads();
   for (int idx = tid; idx < NB * NB; idx += 512) {              // mirror inside LDS (diagonal tiles are kept full)
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
       acc_load(D, S + o * LD + o, LD, lane);
 #pragma unroll
       for (int e = 0; e < 16; ++e) M[e] = ((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) == (lane & 31)) ? 1.f : 0.f;
-      float* Xd = Xs + o * LD + o;
+      float* Xd = S + o * LD + o;                               // X_D takes D's place (D lives in registers now)
       const int c0 = kb * NB + o;
 #define FSTEP(J) factor32_step<J>(D, M, Xd, LD, info, c0, lane)
       FSTEP(0); FSTEP(1); FSTEP(2); FSTEP(3); FSTEP(4); FSTEP(5); FSTEP(6); FSTEP(7);
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
       f32x16 acc;
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-      lds_mfma32(acc, S + ri * LD + o, LD, Xs + o * LD + o, LD, 1.f, lane);
+      lds_mfma32(acc, S + ri * LD + o, LD, S + o * LD + o, LD, 1.f, lane);
       acc_store(acc, S + ri * LD + o, LD, lane);
     }
     __syncthreads();
@@ -193,12 +194,15 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
   }
 
   // ---------------------------------- inverse ----------------------------------
+  // S now holds: X_D on the four diagonal 32-blocks (exact zeros above their diagonals), L below them, junk above.
   if (wave < 2) {                                               // X[2p+1, 2p] = -X_C * (L_CA * X_A), 32x32 blocks
     const int a0 = 64 * wave, c0 = a0 + 32;
     f32x16 T;
 #pragma unroll
     for (int e = 0; e < 16; ++e) T[e] = 0.f;
-    lds_mfma32_bn(T, S + c0 * LD + a0, LD, Xs + a0 * LD + a0, LD, 1.f, lane);   // T = L_CA * X_A
+    lds_mfma32_bn(T, S + c0 * LD + a0, LD, S + a0 * LD + a0, LD, 1.f, lane);   // T = L_CA * X_A
+    // X = -X_C * T with T straight from the accumulator registers: MFMA step t takes, in lane half h,
+    // the k index  r(t, h) = (t & 3) + 8 * (t >> 2) + 4 * h  -- the row of T that register t holds
     f32x16 X;
 #pragma unroll
     for (int e = 0; e < 16; ++e) X[e] = 0.f;
@@ -206,10 +210,13 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
       const int k = (t & 3) + 8 * (t >> 2) + 4 * h;
-      const float av = -Xs[(c0 + r) * LD + c0 + k];
+      const float av = -S[(c0 + r) * LD + c0 + k];
       X = __builtin_amdgcn_mfma_f32_32x32x2f32(av, T[t], X, 0, 0, 0);
     }
-    acc_store(X, Xs + c0 * LD + a0, LD, lane);
+    acc_store(X, S + c0 * LD + a0, LD, lane);                   // over L_CA (this wave is its only reader)
+  } else if (wave < 4) {                                        // the blocks above: zero (X_A, X_C are read as 64x64 below)
+    const int a0 = 64 * (wave - 2);
+    for (int idx = lane; idx < 32 * 32; idx += 64) S[(a0 + (idx >> 5)) * LD + a0 + 32 + (idx & 31)] = 0.f;
   }
   __syncthreads();
   if (wave < 4) {                                               // T[64x64] = L[64:128, 0:64] * X[0:64, 0:64]
@@ -219,8 +226,8 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
     for (int e = 0; e < 16; ++e) T[e] = 0.f;
 #pragma unroll
     for (int K = 0; K < 2; ++K)
-      lds_mfma32_bn(T, S + (64 + 32 * I) * LD + 32 * K, LD, Xs + (32 * K) * LD + 32 * J, LD, 1.f, lane);
-    acc_store(T, Tt + (32 * I) * 65 + 32 * J, 65, lane);
+      lds_mfma32_bn(T, S + (64 + 32 * I) * LD + 32 * K, LD, S + (32 * K) * LD + 32 * J, LD, 1.f, lane);
+    acc_store(T, Tt + (32 * I) * LD + 32 * J, LD, lane);
   }
   __syncthreads();
   if (wave < 4) {                                               // X[64:128, 0:64] = -X[64:128, 64:128] * T
@@ -230,29 +237,37 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
     for (int e = 0; e < 16; ++e) X[e] = 0.f;
 #pragma unroll
     for (int K = 0; K < 2; ++K)
-      lds_mfma32_bn(X, Xs + (64 + 32 * I) * LD + 64 + 32 * K, LD, Tt + (32 * K) * 65 + 32 * J, 65, -1.f, lane);
-    acc_store(X, Xs + (64 + 32 * I) * LD + 32 * J, LD, lane);
+      lds_mfma32_bn(X, S + (64 + 32 * I) * LD + 64 + 32 * K, LD, Tt + (32 * K) * LD + 32 * J, LD, -1.f, lane);
+    acc_store(X, S + (64 + 32 * I) * LD + 32 * J, LD, lane);    // over L[64:128, 0:64] (dead since the barrier)
   }
   __syncthreads();
   float* Xk = Linv + (long)kb * NB * Cp + (long)kb * NB;
   for (int idx = tid; idx < NB * NB; idx += 512) {
     const int i = idx >> 7, k = idx & 127;
-    Xk[(long)i * Cp + k] = (k <= i) ? Xs[i * LD + k] : 0.f;
+    Xk[(long)i * Cp + k] = (k <= i) ? S[i * LD + k] : 0.f;
   }
 }
-constexpr size_t POTRF_LDS = sizeof(float) * (2 * NB * (NB + 1) + 64 * 65);
+constexpr size_t POTRF_LDS = sizeof(float) * NB * (NB + 1);
 
 
-// Panel:  P <- P * inv(L_kk)^T  for the block column kb below the diagonal (rows (kb+1)*128 ...).
+// Panel:  P <- P * inv(L_kk)^T  for the block column kb below the diagonal (rows (kb+1)*128 ...), IN PLACE.
+// One workgroup per 64 rows of a block: it forms both 64 x 64 halves of its 64 x 128 result before it stores either
+// (its rows are read by nobody else), i.e. half the serial MFMA time of one workgroup per 128 x 128 block.
 __global__ __launch_bounds__(GEMM_THREADS) void panel_kernel(float* __restrict__ A,
                                                              const float* __restrict__ Linv, int Cp, int kb) {
-  __shared__ __attribute__((aligned(16))) float smem[GEMM_LDS_FLOATS];
-  const int tm = kb + 1 + blockIdx.x;
-  float* P = A + (long)tm * NB * Cp + (long)kb * NB;
+  __shared__ __attribute__((aligned(16))) float smem[GEMM64_LDS_FLOATS];
+  const int tm = kb + 1 + (blockIdx.x >> 1), sm = blockIdx.x & 1;
+  float* P = A + ((long)tm * NB + 64 * sm) * Cp + (long)kb * NB;
   const float* D = Linv + (long)kb * NB * Cp + (long)kb * NB;
-  Operand<float> a{P, Cp, 1, NB, true};
-  Operand<float> b{D, Cp, 1, NB, true};
-  gemm_tile<float, float, true, true>(a, b, 0, NB, smem, Epilogue{P, Cp, 1, EPI_STORE, TRI_ALL, 0.f, 0.f});
+  Operand<float> a{P, Cp, 1, 64, true};
+  Operand<float> b0{D, Cp, 1, 64, true};
+  Operand<float> b1{D + 64L * Cp, Cp, 1, 64, true};
+  f32x16 acc0, acc1;
+  gemm_acc64<float, float, true, true>(a, b0, 0, NB, smem, acc0);
+  gemm_acc64<float, float, true, true>(a, b1, 0, NB, smem, acc1);     // (ends with a barrier: all reads of P are done)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  tile_epilogue64(acc0, Epilogue{P, Cp, 1, EPI_STORE, TRI_ALL, 0.f, 0.f}, 64, 64, wave >> 1, wave & 1, lane);
+  tile_epilogue64(acc1, Epilogue{P + 64, Cp, 1, EPI_STORE, TRI_ALL, 0.f, 0.f}, 64, 64, wave >> 1, wave & 1, lane);
 }
 
 // Trailing update:  A[m][n] -= sum_{k in [k0, k0 + K)} L[m][k] L[n][k]  on the lower tiles (tm >= tn) of the block
@@ -280,6 +295,23 @@ __global__ __launch_bounds__(GEMM_THREADS) void syrk_kernel(float* __restrict__ 
   const bool diag = diag_blk && sm == sn;
   gemm_tile64<float, float, true, true>(a, b, 0, K, smem,
                                         Epilogue{Ct, Cp, 1, EPI_SUB, diag ? TRI_LOWER : TRI_ALL, 0.f, 0.f});
+}
+// The same update with one workgroup per 128 x 128 block (67 KB of LDS, two per compute unit): for the FAR updates on the
+// helper stream.  Same rate at K = 512 (95 TFLOP/s), but one finishing workgroup frees a slot any kernel of the
+// caller's stream fits into; with four 35 KB workgroups per compute unit the 66 KB diagonal factorization waited for
+// two of them to end together (measured 116 us per diagonal block instead of 40 at C = 16384).
+__global__ __launch_bounds__(GEMM_THREADS) void syrk128_kernel(float* __restrict__ A, int Cp, int nblk, int k0, int K,
+                                                               int tn0, int tn1) {
+  __shared__ __attribute__((aligned(16))) float smem[GEMM_LDS_FLOATS];
+  int rest = blockIdx.x, tn = tn0;
+  while (rest >= nblk - tn) { rest -= nblk - tn; ++tn; }
+  if (tn >= tn1) return;
+  const int tm = tn + rest;
+  const long r0 = (long)tm * NB, c0 = (long)tn * NB;
+  Operand<float> a{A + r0 * Cp + k0, Cp, 1, NB, true};
+  Operand<float> b{A + c0 * Cp + k0, Cp, 1, NB, true};
+  gemm_tile<float, float, true, true>(a, b, 0, K, smem,
+                                      Epilogue{A + r0 * Cp + c0, Cp, 1, EPI_SUB, tm == tn ? TRI_LOWER : TRI_ALL, 0.f, 0.f});
 }
 static inline int syrk_tiles(int nblk, int tn0, int tn1) {       // sum_{tn in [tn0, tn1)} (nblk - tn)
   const int n = tn1 - tn0;
@@ -381,7 +413,7 @@ extern "C" int gptq_hinv_upper(float* H, int ldh, int C, float percdamp, const i
       potrf_inv_diag_kernel<<<1, 512, POTRF_LDS, s>>>(A, Linv, Cp, kb, info);
       const int nrem = nblk - kb - 1;
       if (nrem <= 0) break;
-      panel_kernel<<<nrem, GEMM_THREADS, 0, s>>>(A, Linv, Cp, kb);
+      panel_kernel<<<2 * nrem, GEMM_THREADS, 0, s>>>(A, Linv, Cp, kb);
       if (kb + 1 < p1)                                             // the rest of this outer panel: rank-128
         syrk_kernel<<<dim3(syrk_tiles(nblk, kb + 1, p1), 4), GEMM_THREADS, 0, s>>>(A, Cp, nblk, kb * NB, NB, kb + 1, p1);
     }
@@ -399,7 +431,7 @@ extern "C" int gptq_hinv_upper(float* H, int ldh, int C, float percdamp, const i
           GPTQ_CHECK_HIP(hipStreamWaitEvent(sc->stream, sc->main_done, 0));
           ts = sc->stream;
         }
-        syrk_kernel<<<dim3(syrk_tiles(nblk, q1, nblk), 4), GEMM_THREADS, 0, ts>>>(A, Cp, nblk, p0 * NB, (p1 - p0) * NB, q1, nblk);
+        syrk128_kernel<<<syrk_tiles(nblk, q1, nblk), GEMM_THREADS, 0, ts>>>(A, Cp, nblk, p0 * NB, (p1 - p0) * NB, q1, nblk);
         if (sc) {
           GPTQ_CHECK_HIP(hipEventRecord(sc->side_done, sc->stream));
           side_busy = true;

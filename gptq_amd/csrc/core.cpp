@@ -1,6 +1,7 @@
 // Error reporting and ABI version of libgptq_hip.so.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdint.h>
 #include <stdlib.h>
 
 #include <map>
@@ -27,7 +28,15 @@ SideCtx* side_ctx(hipStream_t main) {
   for (const auto& kv : table) mine += kv.first.first == dev;
   if (mine >= limit) return nullptr;
   SideCtx c;
-  if (hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  // Lowest priority: the helper stream carries the big rank-512 updates (thousands of workgroups) that run underneath
+  // the caller's stream, whose kernels are small, serial and on the critical path.  Priority decides who gets a freed
+  // slot first; it does not preempt, so those updates are launched as two 67 KB workgroups per compute unit: ONE
+  // finishing workgroup then frees enough LDS for any of the caller's kernels (the diagonal factorization needs 66 KB).
+  // (Tried: confining the helper stream to a subset of the compute units with a queue CU mask -- every solve got
+  // 35-50 % slower, masked queues cost more than the contention they remove.)
+  int least = 0, greatest = 0;
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+  if (hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, least) != hipSuccess) return nullptr;
   if (hipEventCreateWithFlags(&c.main_done, hipEventDisableTiming) != hipSuccess) return nullptr;
   if (hipEventCreateWithFlags(&c.side_done, hipEventDisableTiming) != hipSuccess) return nullptr;
   if (hipEventCreateWithFlags(&c.prep_done, hipEventDisableTiming) != hipSuccess) return nullptr;

@@ -395,6 +395,20 @@ __global__ __launch_bounds__(GEMM_THREADS) void trailing_kernel(float* __restric
   gemm_tile64<float, float, true, false>(a, b, 0, K, smem, Epilogue{Wt, ldw, 1, EPI_SUB, TRI_ALL, 0.f, 0.f});
 }
 
+// The same update with one workgroup per 128 x 128 tile (67 KB of LDS, two per compute unit): for the FAR updates on the
+// helper stream -- one finishing workgroup then frees a slot that any kernel of the caller's stream fits into (see
+// core.cpp, side_ctx).
+__global__ __launch_bounds__(GEMM_THREADS) void trailing128_kernel(float* __restrict__ W, int ldw, int R, int c_begin,
+                                                                   int c_end, const float* __restrict__ E, int lde,
+                                                                   int K, const float* __restrict__ U, int ldu, int u0,
+                                                                   bool bvec) {
+  __shared__ __attribute__((aligned(16))) float smem[GEMM_LDS_FLOATS];
+  const long r0 = (long)blockIdx.y * GBM, c0 = (long)c_begin + (long)blockIdx.x * GBN;
+  Operand<float> a{E + r0 * lde, lde, 1, (int)min((long)GBM, R - r0), (lde % 4) == 0};
+  Operand<float> b{U + (long)u0 * ldu + c0, 1, ldu, (int)min((long)GBN, c_end - c0), bvec};
+  gemm_tile<float, float, true, false>(a, b, 0, K, smem, Epilogue{W + r0 * ldw + c0, ldw, 1, EPI_SUB, TRI_ALL, 0.f, 0.f});
+}
+
 }  // namespace gptq
 
 using namespace gptq;
@@ -658,7 +672,7 @@ extern "C" int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R
           GPTQ_CHECK_HIP(hipStreamWaitEvent(sc->stream, sc->main_done, 0));
           ts = sc->stream;
         }
-        trailing_kernel<<<dim3(cdiv(C - next_end, SBN), cdiv(R, SBM)), GEMM_THREADS, 0, ts>>>(
+        trailing128_kernel<<<dim3(cdiv(C - next_end, GBN), cdiv(R, GBM)), GEMM_THREADS, 0, ts>>>(
             Wk, ldk, R, next_end, C, ErrS, SB, s1 - s0, H, ldh, s0, bvec_base && (next_end % 4 == 0));
         if (sc) {
           GPTQ_CHECK_HIP(hipEventRecord(sc->side_done, sc->stream));

@@ -98,19 +98,18 @@ __device__ __forceinline__ void tile_epilogue64(const f32x16& acc, const Epilogu
   }
 }
 
-// C_tile(64 x 64) = sum_{k in [k_begin, k_end)} A(m,k) * B(n,k), combined with memory as `ep` says.  The k order of
-// every output element is the same ascending fmaf chain as gemm_tile's: bit-identical results.
-// `smem` must hold GEMM64_LDS_FLOATS floats.
+// acc(64 x 64 tile, this wave's 32 x 32 part) = sum_{k in [k_begin, k_end)} A(m,k) * B(n,k).  The k order of every
+// output element is the same ascending fmaf chain as gemm_tile's: bit-identical results.  Ends with a workgroup
+// barrier (every wave is done with `smem` and with its global reads).  `smem` must hold GEMM64_LDS_FLOATS floats.
 template <typename TA, typename TB, bool AKC, bool BKC>
-__device__ __forceinline__ void gemm_tile64(const Operand<TA>& a, const Operand<TB>& b, int k_begin, int k_end,
-                                            float* smem, const Epilogue& ep) {
+__device__ __forceinline__ void gemm_acc64(const Operand<TA>& a, const Operand<TB>& b, int k_begin, int k_end,
+                                           float* smem, f32x16& acc) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   float* As = smem;
   float* Bs = smem + 2 * GBK * 68;
-  f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
   float ra[SGST][4], rb[SGST][4];
@@ -144,7 +143,16 @@ __device__ __forceinline__ void gemm_tile64(const Operand<TA>& a, const Operand<
     __syncthreads();
     cur ^= 1;
   }
-  tile_epilogue64(acc, ep, a.rem, b.rem, wm, wn, lane);
+}
+
+// C_tile(64 x 64) = the product above, combined with memory as `ep` says.
+template <typename TA, typename TB, bool AKC, bool BKC>
+__device__ __forceinline__ void gemm_tile64(const Operand<TA>& a, const Operand<TB>& b, int k_begin, int k_end,
+                                            float* smem, const Epilogue& ep) {
+  f32x16 acc;
+  gemm_acc64<TA, TB, AKC, BKC>(a, b, k_begin, k_end, smem, acc);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  tile_epilogue64(acc, ep, a.rem, b.rem, wave >> 1, wave & 1, lane);
 }
 
 }  // namespace gptq
