@@ -106,6 +106,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary measurement on the other headline config")
     ap.add_argument("--also-steps", type=int, default=2)
+    ap.add_argument("--ppl-proxy", action="store_true",
+                    help="add `ppl_proxy`: our OPT driver + evaluator vs the reference's numbers on the random-init OPT-125m "
+                         "architecture of tests/golden/g6_opt125m.npz (a proxy: no Wiki2 / checkpoints offline)")
     return ap.parse_args()
 
 
@@ -351,6 +354,15 @@ def main():
         if cpu is not None:
             out["gpu_over_cpu"] = {"whole_path": round(out["value"] / cpu["value"], 1),
                                    "solve_only": round(out["phases"]["solve_only_mparams_per_s"] / cpu["solve_only_mparams_per_s"], 1)}
+    if rank == 0 and world == 1 and args.ppl_proxy:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from test_gpu_driver import run_ppl_proxy
+        gmod.HESSIAN_DEFER = 1
+        r = run_ppl_proxy(dev)
+        out["ppl_proxy"] = {"model": "OPT-125m architecture, random init (seed 0), vocab 2048, 32 x 2048 synthetic calibration tokens, 4-bit",
+                            "ppl_fp": r["ppl_fp"], "ppl_rtn4": r["ppl_rtn4"], "ppl_gptq4": r["ppl_gptq4"],
+                            "reference": r["ref"], "abs_delta_ppl_gptq4": abs(r["ppl_gptq4"] - r["ref"]["ppl_gptq4"]),
+                            "note": "reference numbers = /root/reference opt_sequential + opt_eval on CPU (oracle/gen_golden_opt125m.py); proxy, not Wiki2"}
     if rank == 0:
         sys.stdout.flush()
         with os.fdopen(json_fd, "w") as real_stdout:

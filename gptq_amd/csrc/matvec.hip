@@ -157,6 +157,179 @@ __global__ __launch_bounds__(256) void matvec_kernel(const TV* __restrict__ vec,
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Second generation: TWO weights per decode instruction, no convert.
+// A packed code c sitting at bit p of a 16-bit half, OR-ed into the mantissa of the fp16 constant 1024.0 (0x6400), IS the
+// fp16 number 1024 + c * 2^p -- no extract, no convert.  One v_and_or_b32 on a 32-bit window of the packed stream
+// therefore turns two codes (one per half) into a half2, and v_fma_mix_f32 multiplies either half (op_sel) with an fp32
+// activation and adds to an fp32 accumulator: window + and_or + 2 fma = 2 full-rate instructions per weight instead
+// of 3 (bfe + cvt + fma).  The activations are pre-scaled by 2^-p per slot while the x chunk is staged in LDS (once per
+// workgroup, shared by all 256 columns, exact) and the constant part sum(1024 * 2^-p * x) is removed at the end;
+// the codes sit at bits 5..7 of their halves (4-bit: 6), so that part is at most 8-32x (16x) the signal per unit of x.
+// (Tried first: v_dot2c_f32_f16 on activation pairs split into two fp16 halves -- fewer instructions still, 1.4-1.9 per
+// weight, but no faster than the old kernel: dot2 issues at a quarter of the fma rate.)
+// Windows: 3-bit pairs (j, j+5) [15 bits apart] for j in 0..4 and 10..14, (j, j+6) [18 bits] for j in 20..25 -- together
+// all 32 codes of a 96-bit group; 4-bit pairs are nibbles (k, k+4) of one word.
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+
+struct PairSlot { int jlo, jhi, plo, phi, s; };     // codes, their bit positions inside the halves, window start bit
+__host__ __device__ constexpr PairSlot pair3(int t) {
+  // t in [0, 16): blocks A (0..4), B (5..9): (j, j+5), lo at p, hi at p - 1;  block C (10..15): (j, j+6), hi at p + 2
+  // positions as high in the mantissa as they go: the constant part is 1024 * 2^-p per unit of x (8, 16 or 32 here)
+  if (t < 5) { const int j = t, p = 7; return PairSlot{j, j + 5, p, p - 1, 3 * j - p}; }
+  if (t < 10) { const int j = 10 + (t - 5), p = 7; return PairSlot{j, j + 5, p, p - 1, 3 * j - p}; }
+  { const int j = 20 + (t - 10), p = 5; return PairSlot{j, j + 6, p, p + 2, 3 * j - p}; }
+}
+__host__ __device__ constexpr PairSlot pair4(int t) {
+  // t in [0, 16): word t / 4, nibbles (k, k + 4), both at bit 6 of their halves: window = word shifted by 4k - 6
+  const int word = t >> 2, k = t & 3;
+  return PairSlot{8 * word + k, 8 * word + k + 4, 6, 6, 32 * word + 4 * k - 6};
+}
+template <int BITS> __host__ __device__ constexpr PairSlot pair_slot(int t) { return BITS == 3 ? pair3(t) : pair4(t); }
+
+// the 32-bit window of the group's bit stream that starts at bit s (may start before bit 0 or run past the end: zeros)
+template <int BITS, int S>
+__device__ __forceinline__ uint32_t stream_window(const uint32_t (&w)[BITS]) {
+  constexpr int NBIT = 32 * BITS;
+  if constexpr (S < 0) return w[0] << (-S);
+  else if constexpr (S % 32 == 0) return w[S / 32];
+  else if constexpr (S / 32 + 1 < BITS && S + 32 <= NBIT) return __builtin_amdgcn_alignbit(w[S / 32 + 1], w[S / 32], S % 32);
+  else return w[S / 32] >> (S % 32);
+}
+
+template <int BITS, int T>
+__device__ __forceinline__ void dot_pairs(const uint32_t (&w)[BITS], const float* __restrict__ xp, uint32_t magic,
+                                          float& acc) {
+  if constexpr (T < 16) {
+    constexpr PairSlot ps = pair_slot<BITS>(T);
+    constexpr uint32_t FM = (1u << BITS) - 1;
+    constexpr uint32_t mask = (FM << ps.plo) | (FM << (16 + ps.phi));
+    // one instruction (hipcc splits `(x & mask) | magic` into v_and + v_or: two 32-bit literals do not fit a VOP3 encoding;
+    // with the mask in an SGPR and the magic in a VGPR it does)
+    uint32_t q;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(q) : "v"(stream_window<BITS, ps.s>(w)), "s"(mask), "v"(magic));
+    // fp16 (low / high half of q) x fp32 + fp32 in one instruction; the product is exact, one rounding at the add
+    // (hipcc emits v_cvt_f32_f16 + v_fmac for fmaf((float)h, x, acc): hence the inline asm)
+    const float x0 = xp[2 * T], x1 = xp[2 * T + 1];
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(q), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(q), "v"(x1));
+    dot_pairs<BITS, T + 1>(w, xp, magic, acc);
+  }
+}
+
+// Workgroup = 256 columns x KG groups of 32 inputs (KG = 8 by default); its four waves take groups wave, wave + 4, ...
+// and keep the packed words of MV_PF groups in flight (1 KiB per load instruction and wave), issued before x is staged.
+constexpr int MV_PF = 2;
+constexpr int MV2_KG_MAX = 128;
+static inline size_t matvec2_lds_bytes(int kg) { return sizeof(float) * ((size_t)kg * (32 + 32 + 2) + 4 * 257); }
+
+template <int BITS, typename TV, bool GROUPED>
+__global__ __launch_bounds__(256) void matvec2_kernel(const TV* __restrict__ vec, const int32_t* __restrict__ mat,
+                                                      float* __restrict__ mul, const float* __restrict__ scales,
+                                                      const float* __restrict__ zeros, int ngroups, int width,
+                                                      int groupsize, int KG) {
+  extern __shared__ __attribute__((aligned(16))) float mv_lds[];
+  float* XP = mv_lds;                                     // [KG][16][2] activations of the pair slots, times 2^-p
+  float* xs = XP + KG * 32;                               // [KG][32] the x chunk in stream order
+  float* Tg = xs + KG * 32;                               // [KG] constant part per group: sum 1024 * 2^-p * x
+  float* Sg = Tg + KG;                                    // [KG] sum of x per group (zero-point term)
+  float* red = Sg + KG;                                   // [4][257]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g0 = blockIdx.y * KG;
+  const int ng = min(KG, ngroups - g0);
+  const int col = (blockIdx.x * 64 + lane) * 4;
+
+  // the packed words of this wave's first MV_PF groups go out first: their latency overlaps the staging of x below
+  auto fetch = [&](int g, uint32_t (&w)[BITS][4]) {
+    const int32_t* p = mat + ((long)(g0 + g) * BITS) * width + col;
+#pragma unroll
+    for (int r = 0; r < BITS; ++r) {
+      const uint4 q = *reinterpret_cast<const uint4*>(p + (long)r * width);
+      w[r][0] = q.x; w[r][1] = q.y; w[r][2] = q.z; w[r][3] = q.w;
+    }
+  };
+  uint32_t ring[MV_PF][BITS][4];
+  if (col < width) {
+#pragma unroll
+    for (int i = 0; i < MV_PF; ++i)
+      if (wave + 4 * i < ng) fetch(wave + 4 * i, ring[i]);
+  }
+
+  // ---- stage x in fp32, then the pre-scaled pair table ----
+  for (int k = tid; k < KG * 32; k += 256) xs[k] = (k < ng * 32) ? mv_to_f32<TV>(vec[(long)g0 * 32 + k]) : 0.f;
+  __syncthreads();
+  {
+    const int t = tid & 15;
+    int jlo = 0, jhi = 0, plo = 0, phi = 0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (u == t) { const PairSlot ps = pair_slot<BITS>(u); jlo = ps.jlo; jhi = ps.jhi; plo = ps.plo; phi = ps.phi; }
+    for (int slot = tid; slot < KG * 16; slot += 256) {   // (KG * 16 is a multiple of 16: whole groups per 16 lanes)
+      const int g = slot >> 4;
+      const float a = ldexpf(xs[g * 32 + jlo], -plo), b = ldexpf(xs[g * 32 + jhi], -phi);   // exact
+      XP[2 * slot] = a;
+      XP[2 * slot + 1] = b;
+      float tpart = 1024.f * (a + b);
+      float spart = xs[g * 32 + 2 * t] + xs[g * 32 + 2 * t + 1];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { tpart += __shfl_xor(tpart, o); spart += __shfl_xor(spart, o); }
+      if (t == 0) { Tg[g] = tpart; Sg[g] = spart; }
+    }
+  }
+  __syncthreads();
+
+  uint32_t magic = 0x64006400u;                            // half2(1024, 1024), kept in a VGPR (see dot_pairs)
+  asm volatile("" : "+v"(magic));
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float tot[4] = {0.f, 0.f, 0.f, 0.f};
+  float twave = 0.f;
+  if (col < width) {
+    for (int base = wave; base < ng; base += 4 * MV_PF) {
+#pragma unroll
+      for (int i = 0; i < MV_PF; ++i) {
+        const int g = base + 4 * i;
+        if (g < ng) {                                        // wave-uniform
+          if (GROUPED) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[v] = 0.f;
+          }
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            uint32_t wc[BITS];
+#pragma unroll
+            for (int r = 0; r < BITS; ++r) wc[r] = ring[i][r][v];
+            dot_pairs<BITS, 0>(wc, XP + g * 32, magic, acc[v]);
+          }
+          if (GROUPED) {
+            const long trow = (long)(((g0 + g) * 32) / groupsize) * width + col;
+            const float tg = Tg[g], sx = Sg[g];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) tot[v] += scales[trow + v] * (acc[v] - tg) - zeros[trow + v] * sx;
+          } else {
+            twave += Tg[g];
+          }
+          if (g + 4 * MV_PF < ng) fetch(g + 4 * MV_PF, ring[i]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < 4; ++v) red[wave * 257 + lane * 4 + v] = GROUPED ? tot[v] : acc[v] - twave;
+  __syncthreads();
+  const int c = blockIdx.x * 256 + tid;
+  if (c < width) {
+    const float q = red[tid] + red[257 + tid] + red[2 * 257 + tid] + red[3 * 257 + tid];
+    if (GROUPED) {
+      atomicAdd(&mul[c], q);
+    } else {
+      float sx = 0.f;
+      for (int g = 0; g < ng; ++g) sx += Sg[g];
+      atomicAdd(&mul[c], scales[c] * q - zeros[c] * sx);
+    }
+  }
+}
+
 template <int BITS>
 static int launch_matvec(const void* vec, int vec_dtype, const int32_t* mat, float* mul, const float* scales,
                          const float* zeros, int height, int width, int groupsize, hipStream_t s, const char* who) {
@@ -167,6 +340,32 @@ static int launch_matvec(const void* vec, int vec_dtype, const int32_t* mat, flo
   const int ngroups = height / BITS;
   const bool v4 = (width % 4 == 0) && (reinterpret_cast<uintptr_t>(mat) % 16 == 0);
   const int vw = v4 ? 4 : 1;
+  if (v4) {                                             // two-weights-per-instruction kernel (fp16 magic + dot2)
+    // 8 groups of 32 inputs per workgroup (two per wave, both in flight from the first instruction on): measured best
+    // on the FC2 shape, kernel time from rocprofv3 -- 8: 28.4 us, 16: 30.3, 32-80 with a 4-deep refill ring: 33-35
+    // (3-bit, fp32 x).  What bounds it is vector issue, not HBM: window + and_or + 2 fma_mix = 4 + 4 + 8 + 8 cycles
+    // per two weights and SIMD, 340 M weights -> 29 us; nontemporal loads were slower (34 us) on this MALL-resident shape.
+    static const int kg2_env = [] { const char* e = getenv("GPTQ_MV_KGROUPS"); return e ? atoi(e) : 0; }();
+    const int colblocks = cdiv(width, 256);
+    int kg = kg2_env > 0 ? std::min(kg2_env, MV2_KG_MAX) : 8;
+    kg = std::max(1, std::min(kg, ngroups));
+    const dim3 grid2(colblocks, cdiv(ngroups, kg));
+    GPTQ_CHECK_ARG(grid2.y <= 65535, "%s: too many input groups", who);
+    const size_t lds = matvec2_lds_bytes(kg);
+#define MV2_LAUNCH(TV)                                                                                             \
+  do {                                                                                                             \
+    if (groupsize > 0)                                                                                             \
+      matvec2_kernel<BITS, TV, true><<<grid2, 256, lds, s>>>(static_cast<const TV*>(vec), mat, mul, scales, zeros, \
+                                                             ngroups, width, groupsize, kg);                       \
+    else                                                                                                           \
+      matvec2_kernel<BITS, TV, false><<<grid2, 256, lds, s>>>(static_cast<const TV*>(vec), mat, mul, scales,       \
+                                                              zeros, ngroups, width, groupsize, kg);               \
+  } while (0)
+    if (vec_dtype == GPTQ_F32) MV2_LAUNCH(float); else MV2_LAUNCH(__half);
+#undef MV2_LAUNCH
+    GPTQ_CHECK_LAUNCH(who);
+    return GPTQ_OK;
+  }
   static const int kg_env = [] { const char* e = getenv("GPTQ_MV_KGROUPS"); return e ? atoi(e) : 0; }();
   int kgroups = kg_env > 0 ? std::min(kg_env, MV_KGROUPS_MAX) : 16;   // measured best on the 36864 x 9216 FC2 shape
   const dim3 grid(cdiv(width, 64 * vw), cdiv(ngroups, kgroups));

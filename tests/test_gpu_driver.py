@@ -125,6 +125,63 @@ def test_opt125m_config1_end_to_end(hip_device):
     assert np.isfinite(ppl_q) and abs(ppl_q - ppl_fp) / ppl_fp < 0.02
 
 
+def opt125m_proxy_model():
+    """The model of oracle/gen_golden_opt125m.py: OPT-125m architecture, vocabulary cut to 2048, fp32, seed 0 (CPU RNG)."""
+    from transformers import OPTConfig, OPTForCausalLM
+    cfg = OPTConfig(vocab_size=2048, hidden_size=768, ffn_dim=3072, num_hidden_layers=12, num_attention_heads=12,
+                    max_position_embeddings=2048, word_embed_proj_dim=768, do_layer_norm_before=True,
+                    dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, layerdrop=0.0)
+    torch.manual_seed(0)
+    m = OPTForCausalLM(cfg).float().eval()
+    m.seqlen = 2048
+    return m
+
+
+def run_ppl_proxy(dev):
+    """PPL-proxy at BASELINE configs[0] size: our driver + evaluator on the GPU vs the numbers the REFERENCE's
+    opt_sequential / opt_eval produced on CPU for the same random-init model and tokens (tests/golden/g6_opt125m.npz).
+    Returns a dict of both sides.  A proxy: Wiki2 and real checkpoints are not available offline."""
+    import gptq_amd.gptq as gmod
+    from gptq_amd.sequential import QuantArgs, eval_ppl, opt_sequential
+    gmod.VERBOSE = False
+    g = load_golden("g6_opt125m")
+    calib = torch.from_numpy(g["calib"].astype(np.int64))
+    test = torch.from_numpy(g["test"].astype(np.int64))
+    out = {"ref": {k: float(g[k]) for k in ("ppl_fp", "ppl_rtn4", "ppl_gptq4")}, "ref_errors": g["errors"]}
+    out["ppl_fp"] = eval_ppl(opt125m_proxy_model(), test, dev)
+    out["ppl_rtn4"] = eval_ppl(opt125m_proxy_model(), test, dev, QuantArgs(wbits=4, nearest=True))
+    model = opt125m_proxy_model()
+    t0 = time.time()
+    opt_sequential(model, [(calib[i], None) for i in range(calib.shape[0])], dev,
+                   QuantArgs(wbits=4, nsamples=calib.shape[0], groupsize=-1, static_groups=True))
+    torch.cuda.synchronize()
+    out["quant_seconds"] = time.time() - t0
+    out["errors"] = np.array([r["error"] for r in opt_sequential.__globals__["quantize_sequential"].last_records])
+    out["ppl_gptq4"] = eval_ppl(model, test, dev)
+    return out
+
+
+def test_opt125m_ppl_proxy_vs_reference(hip_device):
+    r = run_ppl_proxy(hip_device)
+    ref = r["ref"]
+    d_fp, d_rtn, d_q = (abs(r[k] - ref[k]) for k in ("ppl_fp", "ppl_rtn4", "ppl_gptq4"))
+    rel = np.abs(r["errors"] - r["ref_errors"]) / np.abs(r["ref_errors"])
+    print(f"OPT-125m-arch PPL proxy: fp {r['ppl_fp']:.4f} (ref {ref['ppl_fp']:.4f}), rtn4 {r['ppl_rtn4']:.4f} "
+          f"(ref {ref['ppl_rtn4']:.4f}), gptq4 {r['ppl_gptq4']:.4f} (ref {ref['ppl_gptq4']:.4f}); |dPPL| gptq4 {d_q:.4f}; "
+          f"per-Linear error rel diff: first block max {rel[:6].max():.2e}, all max {rel.max():.2e}; "
+          f"quantization {r['quant_seconds']:.1f} s")
+    from conftest import record_parity
+    record_parity("ppl_proxy_opt125m_arch", ppl_fp=r["ppl_fp"], ppl_rtn4=r["ppl_rtn4"], ppl_gptq4=r["ppl_gptq4"],
+                  ref_ppl_fp=ref["ppl_fp"], ref_ppl_rtn4=ref["ppl_rtn4"], ref_ppl_gptq4=ref["ppl_gptq4"],
+                  abs_dppl_gptq4=d_q, max_rel_error_first_block=float(rel[:6].max()), max_rel_error_all=float(rel.max()))
+    assert len(r["errors"]) == len(r["ref_errors"]) == 72
+    # GPU vs CPU forward rounding on a random-init model with PPL ~ vocabulary size: relative bars
+    assert d_fp <= 1e-3 * ref["ppl_fp"] and d_rtn <= 1e-3 * ref["ppl_rtn4"]
+    assert d_q <= 2e-3 * ref["ppl_gptq4"]
+    assert rel[:6].max() <= 2e-3          # first block: same inputs up to forward rounding
+    assert rel.max() <= 1e-1
+
+
 def _clone_fp(cfg):
     from transformers import OPTForCausalLM
     torch.manual_seed(0)
