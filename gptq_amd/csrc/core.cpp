@@ -33,7 +33,8 @@ SideCtx* side_ctx(hipStream_t main) {
   // slot first; it does not preempt, so those updates are launched as two 67 KB workgroups per compute unit: ONE
   // finishing workgroup then frees enough LDS for any of the caller's kernels (the diagonal factorization needs 66 KB).
   // (Tried: confining the helper stream to a subset of the compute units with a queue CU mask -- every solve got
-  // 35-50 % slower, masked queues cost more than the contention they remove.)
+  // 35-50 % slower, masked queues cost more than the contention they remove; capping the updates' grids at one or two
+  // workgroups per compute unit with a tile loop -- no gain at two, slower at one.)
   int least = 0, greatest = 0;
   if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
   if (hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, least) != hipSuccess) return nullptr;

@@ -200,6 +200,7 @@ struct QuantBlockArgs {
   float maxq;
   float* Err; uint8_t* codes; int ldc; const int32_t* col_map; float* loss;
   int lde;   // leading dimension of Err (>= blocksize): Err1 of this block is Err[r * lde + 0 .. blocksize)
+  int errw;  // = blocksize: Err columns [count, errw) are zeroed (the kernel's own width 32 * NPH may be larger)
 };
 
 // One 32-column phase PH of the block (compile-time, so every "is there a later group" test and every
@@ -326,7 +327,7 @@ __device__ __forceinline__ void quant_phase(const QuantBlockArgs& a, float (&w)[
         wrow[col] = w[8 * ph + t];
         if (a.codes) a.codes[rbase * a.ldc + cmap[col]] = (uint8_t)cd[t];
       }
-      a.Err[rbase * a.lde + col] = (col < a.count) ? e[t] : 0.f;
+      if (col < a.errw) a.Err[rbase * a.lde + col] = (col < a.count) ? e[t] : 0.f;
     }
   }
   if (PH + 1 < NPH) stage_store<NPH>(Us_next, tid, nxt);
@@ -389,7 +390,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void trailing_kernel(float* __restric
   __shared__ __attribute__((aligned(16))) float smem[GEMM64_LDS_FLOATS];
   const int tn = blockIdx.x, tm = blockIdx.y;
   const long r0 = (long)tm * SBM, c0 = (long)c_begin + (long)tn * SBN;
-  Operand<float> a{E + r0 * lde, lde, 1, (int)min((long)SBM, R - r0), (lde % 4) == 0};
+  Operand<float> a{E + r0 * lde, lde, 1, (int)min((long)SBM, R - r0),
+                   (lde % 4) == 0 && reinterpret_cast<uintptr_t>(E) % 16 == 0};
   Operand<float> b{U + (long)u0 * ldu + c0, 1, ldu, (int)min((long)SBN, c_end - c0), bvec};
   float* Wt = W + r0 * ldw + c0;
   gemm_tile64<float, float, true, false>(a, b, 0, K, smem, Epilogue{Wt, ldw, 1, EPI_SUB, TRI_ALL, 0.f, 0.f});
@@ -404,7 +406,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void trailing128_kernel(float* __rest
                                                                    bool bvec) {
   __shared__ __attribute__((aligned(16))) float smem[GEMM_LDS_FLOATS];
   const long r0 = (long)blockIdx.y * GBM, c0 = (long)c_begin + (long)blockIdx.x * GBN;
-  Operand<float> a{E + r0 * lde, lde, 1, (int)min((long)GBM, R - r0), (lde % 4) == 0};
+  Operand<float> a{E + r0 * lde, lde, 1, (int)min((long)GBM, R - r0),
+                   (lde % 4) == 0 && reinterpret_cast<uintptr_t>(E) % 16 == 0};
   Operand<float> b{U + (long)u0 * ldu + c0, 1, ldu, (int)min((long)GBN, c_end - c0), bvec};
   gemm_tile<float, float, true, false>(a, b, 0, K, smem, Epilogue{W + r0 * ldw + c0, ldw, 1, EPI_SUB, TRI_ALL, 0.f, 0.f});
 }
@@ -472,15 +475,17 @@ static int launch_quant_block(const QuantBlockArgs& a, int blocksize, bool group
     return GPTQ_OK;
   }
 #endif
+  // any blocksize up to 256 (gptq.py:127 takes any int): the kernel walks ceil(blocksize / 32) phases of 32 columns and
+  // treats the columns past `count` as padding, exactly like the tail block of a matrix
 #define QB_CASE(NPH)                                                                  \
-  case 32 * NPH:                                                                      \
+  case NPH:                                                                           \
     if (grouped) quant_block_kernel<NPH, true><<<grid, 256, 0, s>>>(a);               \
     else quant_block_kernel<NPH, false><<<grid, 256, 0, s>>>(a);                      \
     break;
-  switch (blocksize) {
-    QB_CASE(1) QB_CASE(2) QB_CASE(4) QB_CASE(8)
+  switch (cdiv(blocksize, 32)) {
+    QB_CASE(1) QB_CASE(2) QB_CASE(3) QB_CASE(4) QB_CASE(5) QB_CASE(6) QB_CASE(7) QB_CASE(8)
     default:
-      set_error("blocksize %d unsupported (32, 64, 128 or 256)", blocksize);
+      set_error("blocksize %d unsupported (1 ... 256)", blocksize);
       return GPTQ_ERR_UNSUPPORTED;
   }
 #undef QB_CASE
@@ -496,10 +501,11 @@ extern "C" int gptq_quant_block(float* W, int ldw, int R, int C, int i1, int cou
   GPTQ_CHECK_ARG(W && U && scale_tab && zero_tab && Err && loss, "gptq_quant_block: null pointer");
   GPTQ_CHECK_ARG(R > 0 && C > 0 && i1 >= 0 && count > 0 && count <= blocksize && i1 + count <= C,
                  "gptq_quant_block: bad block range");
+  GPTQ_CHECK_ARG(blocksize >= 1 && blocksize <= 256, "gptq_quant_block: blocksize must be in 1 ... 256");
   GPTQ_CHECK_ARG(ldw >= C && ldu >= C && tab_ld >= 1, "gptq_quant_block: bad leading dimension");
   GPTQ_CHECK_ARG(bits >= 1 && bits <= 8, "gptq_quant_block: bits must be in 1..8");
   QuantBlockArgs a{W, ldw, R, i1, count, U, ldu, scale_tab, zero_tab, tab_ld, col_group,
-                   (float)((1 << bits) - 1), Err, codes, ldc, col_map, loss, blocksize};
+                   (float)((1 << bits) - 1), Err, codes, ldc, col_map, loss, blocksize, blocksize};
   return launch_quant_block(a, blocksize, col_group != nullptr, static_cast<hipStream_t>(stream));
 }
 
@@ -553,8 +559,8 @@ extern "C" int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R
   GPTQ_CHECK_ARG(R <= 65535, "gptq_fasterquant: R too large");
   GPTQ_CHECK_ARG(bits >= 1 && bits <= 8, "gptq_fasterquant: bits must be in 1..8 (trits are out of scope)");
   GPTQ_CHECK_ARG(groupsize == -1 || groupsize > 0, "gptq_fasterquant: groupsize must be -1 or positive");
-  if (blocksize != 32 && blocksize != 64 && blocksize != 128 && blocksize != 256) {
-    set_error("gptq_fasterquant: blocksize %d unsupported (32, 64, 128 or 256)", blocksize);
+  if (blocksize < 1 || blocksize > 256) {
+    set_error("gptq_fasterquant: blocksize %d unsupported (1 ... 256; the reference default is 128)", blocksize);
     return GPTQ_ERR_UNSUPPORTED;
   }
   GPTQ_CHECK_ARG(reinterpret_cast<uintptr_t>(workspace) % 256 == 0, "gptq_fasterquant: workspace must be 256-byte aligned");
@@ -649,7 +655,7 @@ extern "C" int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R
         }
       }
       QuantBlockArgs a{Wk, ldk, R, i1, count, H, ldh, ws.stab, ws.ztab, G,
-                       grouped ? ws.cgroup : nullptr, maxq, Err, codes, C, perm, ws.loss, SB};
+                       grouped ? ws.cgroup : nullptr, maxq, Err, codes, C, perm, ws.loss, SB, blocksize};
       const int rc = launch_quant_block(a, blocksize, grouped, s);
       if (rc != GPTQ_OK) return rc;
       if (i2 < s1)                                                   // the rest of this super-block: rank-blocksize

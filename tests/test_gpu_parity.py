@@ -383,6 +383,34 @@ def test_fasterquant_mid1024_reference_flag_sets(G, name):
     assert rows_same >= R - 4
 
 
+@pytest.mark.parametrize("blocksize,kw", [(100, dict(groupsize=-1)), (96, dict(groupsize=64)), (100, dict(groupsize=64)),
+                                          (160, dict(groupsize=-1, actorder=True)), (17, dict(groupsize=-1)),
+                                          (224, dict(groupsize=128, static_groups=True))])
+def test_fasterquant_any_blocksize_up_to_256(G, O, blocksize, kw):
+    """gptq.py:127 takes any `blocksize`; the column-loop kernel pads every block to a multiple of 32 like a tail block.
+    Yardstick: the oracle (bit-identical to the reference on the goldens, any blocksize) on this host's CPU."""
+    gen = torch.Generator().manual_seed(1000 + blocksize)
+    R, C = 48, 330
+    W = (torch.randn(R, C, generator=gen) * 0.02).half().float()
+    H, n = torch.zeros(C, C), 0
+    for _ in range(3):
+        n = O.hessian_add_batch(H, n, (torch.randn(1, 2 * C, C, generator=gen) * (1 + torch.arange(C) % 7)).half())
+    full = dict(percdamp=0.01, groupsize=-1, actorder=False, static_groups=False)
+    full.update(kw)
+    ref = O.fasterquant(W, H, bits=4, sym=False, blocksize=blocksize, **full)
+    lin, gp = _run_gptq(G, W, H, n, bits=4, sym=False, blocksize=blocksize, **full)
+    flipped = int((gp.codes.cpu().int() != ref.codes).sum())
+    rel = relfro(lin.weight.data.cpu(), ref.Q)
+    print(f"blocksize {blocksize} {kw}: flipped codes {flipped}/{R * C}, relFro {rel:.2e}, error {gp.error:.6g} vs {ref.error:.6g}")
+    assert flipped <= 2 and rel <= 1e-3
+    assert abs(gp.error - ref.error) <= 1e-3 * abs(ref.error)
+    gp2 = G.GPTQ(make_linear(W.cuda()))
+    gp2.quantizer = G.Quantizer(); gp2.quantizer.configure(4, perchannel=True, sym=False)
+    gp2.H = H.clone().cuda()
+    with pytest.raises(NotImplementedError):
+        gp2.fasterquant(blocksize=512)
+
+
 def test_fasterquant_mid512_codes(G):
     g = load_golden("g3_mid512")
     lin, gp = _run_gptq(G, torch.from_numpy(g["W"]).float(), torch.from_numpy(g["H"]), 2, bits=4, sym=False)
@@ -786,20 +814,20 @@ def _calibrated(G, W, n_samples, seed, bits):
     return lin, gp
 
 
-@pytest.mark.parametrize("R,C", [(4096, 4096), (4096, 11008)])
+@pytest.mark.parametrize("R,C", [(4096, 4096), (4096, 11008), (8192, 22016)])
 def test_full_size_properties_llama7b_actorder(G, hip_device, R, C):
     """BASELINE configs[2]: Llama-7B q/k/v/o (4096 x 4096) and down_proj (4096 x 11008: 43 tiles of 256, 86 blocks of
-    128), 4-bit, per-row grid, --act-order."""
+    128), 4-bit, per-row grid, --act-order; and configs[4]: Llama-65B down_proj (8192 x 22016: 86 tiles, 172 blocks)."""
     G.gptq.VERBOSE = False
     gen = torch.Generator(device="cuda").manual_seed(C)
     W = (torch.randn(R, C, device=hip_device, generator=gen) * 0.02).half()
-    lin, gp = _calibrated(G, W, 6, 100 + C, 4)
+    lin, gp = _calibrated(G, W, max(6, -(-5 * C // (4 * 2048))), 100 + C, 4)   # more tokens than columns: H has full rank
     H = gp.H.clone()
     assert torch.equal(H, H.t())
     gp.fasterquant(blocksize=128, percdamp=0.01, groupsize=-1, actorder=True)
     resid, p_gptq, p_rtn = _full_size_checks(G, W, lin, gp, H, 4, True)
-    record_parity(f"full_llama7b_{R}x{C}_actorder", resid_UtU_H=resid, proxy_gptq=p_gptq, proxy_rtn=p_rtn, error=gp.error)
-    print(f"llama7b {R}x{C} act-order: |U^T U (H+dI) - I|/sqrt(C) = {resid:.2e}, proxy gptq/rtn = {p_gptq / p_rtn:.3f}")
+    record_parity(f"full_llama_{R}x{C}_actorder", resid_UtU_H=resid, proxy_gptq=p_gptq, proxy_rtn=p_rtn, error=gp.error)
+    print(f"llama {R}x{C} act-order: |U^T U (H+dI) - I|/sqrt(C) = {resid:.2e}, proxy gptq/rtn = {p_gptq / p_rtn:.3f}")
     assert resid <= 1e-4
     assert p_gptq < 0.95 * p_rtn
 
