@@ -437,6 +437,8 @@ struct BigPlan {
   int workers;          // workgroups [dp_tiles, dp_tiles + workers)
   int chunk;            // stages per worker run
   float* ws;            // workers x 2 partial tiles of 256 x 256 fp32
+  int item0;            // first work item of THIS launch (launches by rounds, see hessian_launch_big)
+  int item1;            // one past its last work item
 };
 constexpr int BTILE_FLOATS = BT * BT;
 
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(512) void hessian16_big_kernel(ProbGroup pg, BigPla
   // this workgroup's segments: (tile, stages [s0, s1), partial slot or -1 for the direct epilogue)
   // work items: [0, dp_tiles) whole tiles, then `workers` K-split runs; a launch sized for a CU budget has fewer
   // workgroups than items and every workgroup strides over them
-  for (int bid = blockIdx.x; bid < plan.dp_tiles + plan.workers; bid += gridDim.x) {
+  for (int bid = plan.item0 + blockIdx.x; bid < plan.item1; bid += gridDim.x) {
   int run_begin = 0, run_end = 0;
   const bool whole = bid < plan.dp_tiles;
   if (!whole) {
@@ -769,7 +771,7 @@ __global__ __launch_bounds__(512) void hessian16_big16_kernel(ProbGroup pg, BigP
 
   // work items: [0, dp_tiles) whole tiles, then `workers` K-split runs; a launch sized for a CU budget has fewer
   // workgroups than items and every workgroup strides over them
-  for (int bid = blockIdx.x; bid < plan.dp_tiles + plan.workers; bid += gridDim.x) {
+  for (int bid = plan.item0 + blockIdx.x; bid < plan.item1; bid += gridDim.x) {
   int run_begin = 0, run_end = 0;
   const bool whole = bid < plan.dp_tiles;
   if (!whole) {
@@ -1027,7 +1029,7 @@ static int hessian_launch_big(const HostProb* probs, int n_prob, int n_x, int x_
       const int nk_all = tokens / BBK * nx;
       static const int shape_env = [] { const char* e = getenv("GPTQ_HESS_SHAPE"); return e ? atoi(e) : 16; }();
       const bool shape16 = shape_env == 16 && nk_all % 2 == 0;
-      BigPlan plan{total, 0, 0, 1, nullptr};   // dp_tiles, left_tiles, workers, chunk, ws
+      BigPlan plan{total, 0, 0, 1, nullptr, 0, 0};   // dp_tiles, left_tiles, workers, chunk, ws, item0, item1
       const int full = total / n_cu * n_cu, left = total - full;
       // cut the last round along K when it would run under 90 % full and a run still has >= 8 stages
       if (big_env != 3 && left > 0 && left * 10 < n_cu * 9 && (long)left * nk_all >= 8L * n_cu) {
@@ -1040,8 +1042,19 @@ static int hessian_launch_big(const HostProb* probs, int n_prob, int n_x, int x_
         GPTQ_CHECK_ARG(plan.ws != nullptr, "gptq_hessian_accum: cannot allocate the %zu-byte split-K workspace",
                        sizeof(float) * 2 * BTILE_FLOATS * (size_t)plan.workers);
       }
-      int grid = plan.dp_tiles + plan.workers;
-      if (cu_limit > 0) grid = std::min(grid, n_cu);              // a real budget: the workgroups stride over the items
+      // One launch per ROUND of n_cu work items instead of one launch for all of them: the workgroups of a launch start
+      // together, so the tiles an XCD runs side by side walk K in step and share their operand panels in its L2.  In a
+      // single launch the later rounds start one by one as compute units free up; a tile that starts 5 % of a tile
+      // time after its neighbours is 50 stages behind them, far outside what 4 MB of L2 keeps.
+      // (A launch sized for a CU budget keeps the single strided launch.)
+      static const int rounds_env = [] { const char* e = getenv("GPTQ_HESS_ROUNDS"); return e ? atoi(e) : 1; }();
+      const int items = plan.dp_tiles + plan.workers;
+      const bool by_rounds = rounds_env != 0 && cu_limit <= 0;
+      const int per_launch = by_rounds ? n_cu : items;
+      static const int bring_env = [] { const char* e = getenv("GPTQ_HESS_RING"); return e ? atoi(e) : BRING_DEFAULT; }();
+#ifdef GPTQ_DIAG   // timing-only ablation builds exist in the diagnostic library alone (python -m gptq_amd.build --diag)
+      static const int babl_env = [] { const char* e = getenv("GPTQ_HESS_ABLATE"); return e ? atoi(e) : 0; }();
+#endif
 #define HBIG(BF, RG, AB)                                                                                      \
   do {                                                                                                        \
     const size_t lds_b = (size_t)(RG) * BSTAGE;                                                               \
@@ -1049,33 +1062,37 @@ static int hessian_launch_big(const HostProb* probs, int n_prob, int n_x, int x_
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));              \
     hessian16_big_kernel<BF, RG, AB><<<grid, 512, lds_b, s>>>(pg, plan, nx, tokens);                          \
   } while (0)
-      static const int bring_env = [] { const char* e = getenv("GPTQ_HESS_RING"); return e ? atoi(e) : BRING_DEFAULT; }();
-#ifdef GPTQ_DIAG   // timing-only ablation builds exist in the diagnostic library alone (python -m gptq_amd.build --diag)
-      static const int babl_env = [] { const char* e = getenv("GPTQ_HESS_ABLATE"); return e ? atoi(e) : 0; }();
-#endif
-      if (shape16) {
-        const size_t lds_b = (size_t)BRING_DEFAULT * BSTAGE;
-        if (x_dtype == GPTQ_BF16) {
-          GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_big16_kernel<true>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
-          hessian16_big16_kernel<true><<<grid, 512, lds_b, s>>>(pg, plan, nx, tokens);
-        } else {
-          GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_big16_kernel<false>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
-          hessian16_big16_kernel<false><<<grid, 512, lds_b, s>>>(pg, plan, nx, tokens);
+      for (int i0 = 0; i0 < items; i0 += per_launch) {
+        plan.item0 = i0;
+        plan.item1 = std::min(items, i0 + per_launch);
+        int grid = plan.item1 - plan.item0;
+        if (cu_limit > 0) grid = std::min(grid, n_cu);            // a real budget: the workgroups stride over the items
+        if (shape16) {
+          const size_t lds_b = (size_t)BRING_DEFAULT * BSTAGE;
+          if (x_dtype == GPTQ_BF16) {
+            GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_big16_kernel<true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+            hessian16_big16_kernel<true><<<grid, 512, lds_b, s>>>(pg, plan, nx, tokens);
+          } else {
+            GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hessian16_big16_kernel<false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+            hessian16_big16_kernel<false><<<grid, 512, lds_b, s>>>(pg, plan, nx, tokens);
+          }
+          continue;
         }
-        if (plan.left_tiles > 0) hessian16_big16_fixup<<<dim3(plan.left_tiles, 4), 512, 0, s>>>(pg, plan, nk_all);
-        continue;
-      }
-      if (x_dtype == GPTQ_BF16) HBIG(true, BRING_DEFAULT, 0);
+        if (x_dtype == GPTQ_BF16) HBIG(true, BRING_DEFAULT, 0);
 #ifdef GPTQ_DIAG
-      else if (babl_env == 1) HBIG(false, BRING_DEFAULT, 1);
-      else if (babl_env == 2) HBIG(false, BRING_DEFAULT, 2);
+        else if (babl_env == 1) HBIG(false, BRING_DEFAULT, 1);
+        else if (babl_env == 2) HBIG(false, BRING_DEFAULT, 2);
 #endif
-      else if (bring_env == 5) HBIG(false, 5, 0);
-      else HBIG(false, BRING_DEFAULT, 0);
+        else if (bring_env == 5) HBIG(false, 5, 0);
+        else HBIG(false, BRING_DEFAULT, 0);
+      }
 #undef HBIG
-      if (plan.left_tiles > 0) hessian16_big_fixup<<<dim3(plan.left_tiles, 4, 8), 64, 0, s>>>(pg, plan, nk_all);
+      if (plan.left_tiles > 0) {
+        if (shape16) hessian16_big16_fixup<<<dim3(plan.left_tiles, 4), 512, 0, s>>>(pg, plan, nk_all);
+        else hessian16_big_fixup<<<dim3(plan.left_tiles, 4, 8), 64, 0, s>>>(pg, plan, nk_all);
+      }
     }
   }
   GPTQ_CHECK_LAUNCH("hessian16_big_kernel");

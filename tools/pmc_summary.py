@@ -14,8 +14,11 @@ root, C, defer, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[
 KERNELS = {"kernel": "hessian16_big16_kernel", "fixup": "hessian16_big16_fixup"}
 
 
-def mean_skip_first(v):
-    return sum(v[1:]) / max(1, len(v) - 1)
+def mean_skip_first(v, per_launch=1):
+    """Per-LAUNCH mean: a launch is `per_launch` consecutive dispatches (one per round of tiles); the first launch is
+    the warm-up and is skipped."""
+    v = v[per_launch:]
+    return sum(v) / max(1, len(v) // per_launch)
 
 
 counters, durations = collections.defaultdict(dict), {}
@@ -33,10 +36,13 @@ for grp in sorted(os.listdir(root)):
                 if (key, r["Dispatch_Id"]) not in seen:
                     seen.add((key, r["Dispatch_Id"]))
                     dur[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    n_launch = max(1, len(dur.get("fixup", [])) or len(dur["kernel"]))
     for key in vals:
+        per = max(1, len(dur[key]) // n_launch)                  # dispatches of this kernel per launch
         for c, v in vals[key].items():
-            counters[key][c] = mean_skip_first(v)
-        durations.setdefault(key, {})[grp] = mean_skip_first(dur[key])
+            counters[key][c] = mean_skip_first(v, per)
+        durations.setdefault(key, {})[grp] = mean_skip_first(dur[key], per)
+        durations[key]["dispatches_per_launch"] = per
 
 S = 2048
 k, f = counters["kernel"], counters.get("fixup", {})
@@ -54,7 +60,7 @@ res = {
     "fetch_bytes_corrected_x2": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
     "traffic_over_algorithmic": (fetch + write) / alg_bytes,
     "L2_hit_rate": k["TCC_HIT_sum"] / (k["TCC_HIT_sum"] + k["TCC_MISS_sum"]),
-    "kernel_us_in_each_pass": durations["kernel"], "fixup_us_in_each_pass": durations.get("fixup", {}),
+    "kernel_us_per_launch_in_each_pass": durations["kernel"], "fixup_us_in_each_pass": durations.get("fixup", {}),
     "GRBM_GUI_ACTIVE_per_XCD": cycles, "effective_clock_GHz_profiled": cycles / t_us / 1e3,
     "SQ_VALU_MFMA_BUSY_CYCLES": k["SQ_VALU_MFMA_BUSY_CYCLES"],
     "mfma_busy_fraction_of_active_cycles": k["SQ_VALU_MFMA_BUSY_CYCLES"] / (cycles * 1024),
