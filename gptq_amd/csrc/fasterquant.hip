@@ -31,7 +31,7 @@ __global__ void zero_dead_kernel(float* __restrict__ W, int ldw, int R, int C,
                                  const int32_t* __restrict__ dead) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C || !dead[c]) return;
-  W[(long)blockIdx.y * ldw + c] = 0.f;
+  for (long r = blockIdx.y; r < R; r += gridDim.y) W[r * ldw + c] = 0.f;      // (grid.y is capped at 65535 rows)
 }
 
 // perm = argsort(diag, descending), stable on ties (gptq.py:166; torch leaves tie order unspecified).
@@ -57,12 +57,13 @@ __global__ __launch_bounds__(256) void argsort_desc_kernel(const float* __restri
 // dst[r][p] = src[r][perm[p]]  (gather = gptq.py:167)  or  dst[r][perm[p]] = src[r][p] (scatter = :301)
 template <typename T, bool SCATTER>
 __global__ void permute_cols_kernel(const T* __restrict__ src, int lds_, T* __restrict__ dst, int ldd,
-                                    int C, const int32_t* __restrict__ perm) {
+                                    int R, int C, const int32_t* __restrict__ perm) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= C) return;
-  const long r = blockIdx.y;
-  if (SCATTER) dst[r * ldd + perm[p]] = src[r * lds_ + p];
-  else dst[r * ldd + p] = src[r * lds_ + perm[p]];
+  for (long r = blockIdx.y; r < R; r += gridDim.y) {
+    if (SCATTER) dst[r * ldd + perm[p]] = src[r * lds_ + p];
+    else dst[r * ldd + p] = src[r * lds_ + perm[p]];
+  }
 }
 
 // The same through LDS, one workgroup per row at a time: the row is read and written with coalesced 16-byte accesses and
@@ -173,11 +174,12 @@ __global__ void quantize_rows_kernel(float* __restrict__ X, int ldx, int R, int 
                                      const float* __restrict__ scale, const float* __restrict__ zero,
                                      float maxq) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  const int r = blockIdx.y;
   if (c >= C) return;
-  const float s = scale[r], z = zero[r];
-  float* x = X + (long)r * ldx + c;
-  *x = s * (affine_code(*x, s, z, maxq) - z);                  // quant.py:10
+  for (long r = blockIdx.y; r < R; r += gridDim.y) {
+    const float s = scale[r], z = zero[r];
+    float* x = X + r * ldx + c;
+    *x = s * (affine_code(*x, s, z, maxq) - z);                // quant.py:10
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -428,7 +430,7 @@ static int permute_cols(const float* src, int lds_, float* dst, int ldd, int R, 
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     permute_rows_lds_kernel<SCATTER><<<std::min(R, 1024), 512, bytes, s>>>(src, lds_, dst, ldd, R, C, perm);
   } else {
-    permute_cols_kernel<float, SCATTER><<<dim3(cdiv(C, 256), R), 256, 0, s>>>(src, lds_, dst, ldd, C, perm);
+    permute_cols_kernel<float, SCATTER><<<dim3(cdiv(C, 256), std::min(R, 65535)), 256, 0, s>>>(src, lds_, dst, ldd, R, C, perm);
   }
   GPTQ_CHECK_LAUNCH("permute_cols");
   return GPTQ_OK;
@@ -456,8 +458,7 @@ extern "C" int gptq_quantize_rows(float* X, int ldx, int R, int C, const float* 
                                   int bits, gptq_stream_t stream) {
   GPTQ_CHECK_ARG(X && scale && zero && R > 0 && C > 0 && ldx >= C, "gptq_quantize_rows: bad arguments");
   GPTQ_CHECK_ARG(bits >= 1 && bits <= 8, "gptq_quantize_rows: bits must be in 1..8");
-  GPTQ_CHECK_ARG(R <= 65535, "gptq_quantize_rows: R too large");
-  quantize_rows_kernel<<<dim3(cdiv(C, 256), R), 256, 0, static_cast<hipStream_t>(stream)>>>(
+  quantize_rows_kernel<<<dim3(cdiv(C, 256), std::min(R, 65535)), 256, 0, static_cast<hipStream_t>(stream)>>>(
       X, ldx, R, C, scale, zero, (float)((1 << bits) - 1));
   GPTQ_CHECK_LAUNCH("quantize_rows_kernel");
   return GPTQ_OK;
@@ -475,15 +476,18 @@ static int launch_quant_block(const QuantBlockArgs& a, int blocksize, bool group
     return GPTQ_OK;
   }
 #endif
-  // any blocksize up to 256 (gptq.py:127 takes any int): the kernel walks ceil(blocksize / 32) phases of 32 columns and
-  // treats the columns past `count` as padding, exactly like the tail block of a matrix
+  // any blocksize up to 256 (gptq.py:127 takes any int): the kernel walks 1, 2, 4 or 8 phases of 32 columns (the next
+  // power of two: fewer kernel variants to build) and treats the columns past `count` as padding, exactly like the tail
+  // block of a matrix
 #define QB_CASE(NPH)                                                                  \
   case NPH:                                                                           \
     if (grouped) quant_block_kernel<NPH, true><<<grid, 256, 0, s>>>(a);               \
     else quant_block_kernel<NPH, false><<<grid, 256, 0, s>>>(a);                      \
     break;
-  switch (cdiv(blocksize, 32)) {
-    QB_CASE(1) QB_CASE(2) QB_CASE(3) QB_CASE(4) QB_CASE(5) QB_CASE(6) QB_CASE(7) QB_CASE(8)
+  int nph = 1;
+  while (nph * 32 < blocksize) nph *= 2;
+  switch (nph) {
+    QB_CASE(1) QB_CASE(2) QB_CASE(4) QB_CASE(8)
     default:
       set_error("blocksize %d unsupported (1 ... 256)", blocksize);
       return GPTQ_ERR_UNSUPPORTED;
@@ -556,7 +560,7 @@ extern "C" int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R
                                      void* workspace, size_t workspace_bytes, gptq_stream_t stream) {
   GPTQ_CHECK_ARG(W && H && scale_io && zero_io && error_out && workspace, "gptq_fasterquant: null pointer");
   GPTQ_CHECK_ARG(R > 0 && C > 0 && ldw >= C && ldh >= C, "gptq_fasterquant: bad sizes");
-  GPTQ_CHECK_ARG(R <= 65535, "gptq_fasterquant: R too large");
+  GPTQ_CHECK_ARG(R <= 4000000, "gptq_fasterquant: R too large (4,000,000 rows per call)");
   GPTQ_CHECK_ARG(bits >= 1 && bits <= 8, "gptq_fasterquant: bits must be in 1..8 (trits are out of scope)");
   GPTQ_CHECK_ARG(groupsize == -1 || groupsize > 0, "gptq_fasterquant: groupsize must be -1 or positive");
   if (blocksize < 1 || blocksize > 256) {
@@ -587,7 +591,7 @@ extern "C" int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R
     GPTQ_CHECK_HIP(hipStreamWaitEvent(sc->stream, sc->main_done, 0));
     ps = sc->stream;
   }
-  zero_dead_kernel<<<dim3(cdiv(C, TB), R), TB, 0, ps>>>(W, ldw, R, C, ws.dead);
+  zero_dead_kernel<<<dim3(cdiv(C, TB), std::min(R, 65535)), TB, 0, ps>>>(W, ldw, R, C, ws.dead);
   // static groups: grids of the ORIGINAL, uncompensated columns (gptq.py:157-163)
   if (use_static)
     find_params_kernel<<<dim3(cdiv(R, 4), G), 256, 0, ps>>>(W, ldw, R, 0, C, groupsize, maxq, sym,

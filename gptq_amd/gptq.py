@@ -386,8 +386,6 @@ class _JointSolve:
 
     @staticmethod
     def compatible(members):
-        if sum(m.rows for m in members) > 65535:                     # gptq_fasterquant's row limit
-            return False
         q0 = members[0].quantizer
         for m in members:
             q = m.quantizer

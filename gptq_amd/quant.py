@@ -31,7 +31,7 @@ def quantize(x, scale, zero, maxq):
     def per_row(t):   # [R, 1] -- or [R] against a single column -- broadcasts along rows exactly like quant.py:9-10
         return tuple(t.shape) == (x.shape[0], 1) or (t.dim() == 1 and t.numel() == x.shape[0] and x.shape[1] == 1)
     if (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and per_row(scale) and per_row(zero)
-            and ((maxq_i + 1) & maxq_i) == 0 and 0 < maxq_i <= 255 and x.shape[0] <= 65535):
+            and ((maxq_i + 1) & maxq_i) == 0 and 0 < maxq_i <= 255):
         out = x.contiguous().clone()
         s = scale.reshape(-1).to(torch.float32).contiguous()
         z = zero.reshape(-1).to(torch.float32).contiguous()

@@ -136,7 +136,7 @@ int gptq_quant_block(float* W, int ldw, int R, int C, int i1, int count, int blo
  * (n_groups = ceil(C/groupsize)) when groupsize > 0.
  * perm_out (nullable, int32[C]) receives the act-order permutation.
  * codes (nullable, uint8 [R, C]) receives integer codes in original column order.
- * blocksize: any value in 1 ... 256 (gptq.py:127; the drivers use 128); R <= 65535 rows per call.
+ * blocksize: any value in 1 ... 256 (gptq.py:127; the drivers use 128).
  * error_out (device fp32[1]) receives sum(Losses) (gptq.py:294).
  * info (device int32[1], nullable): non-zero if the Hessian was not positive definite.
  * ------------------------------------------------------------------------- */

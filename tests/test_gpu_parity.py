@@ -411,6 +411,24 @@ def test_fasterquant_any_blocksize_up_to_256(G, O, blocksize, kw):
         gp2.fasterquant(blocksize=512)
 
 
+def test_more_than_65535_rows(G, O):
+    """No row cliff: a Linear (or a stack of Linears sharing one Hessian) with more than 65535 output rows."""
+    gen = torch.Generator().manual_seed(65)
+    R, C = 70016, 128
+    W = (torch.randn(R, C, generator=gen) * 0.02).half().float()
+    H, n = torch.zeros(C, C), 0
+    for _ in range(2):
+        n = O.hessian_add_batch(H, n, (torch.randn(1, 512, C, generator=gen) * (1 + torch.arange(C) % 7)).half())
+    ref = O.fasterquant(W, H, bits=4, sym=False, blocksize=128, percdamp=0.01, groupsize=-1, actorder=True, static_groups=False)
+    lin, gp = _run_gptq(G, W, H, n, bits=4, sym=False, blocksize=128, percdamp=0.01, groupsize=-1, actorder=True)
+    flipped = int((gp.codes.cpu().int() != ref.codes).sum())
+    assert flipped <= 8, flipped
+    assert torch.equal(gp.quantizer.scale.cpu(), ref.scale)
+    assert abs(gp.error - ref.error) <= 1e-3 * abs(ref.error)
+    s, z = O.find_params(W, 15, False)
+    assert torch.equal(G.quantize(W.cuda(), s.cuda(), z.cuda(), torch.tensor(15)).cpu(), O.quantize(W, s, z, 15))
+
+
 def test_fasterquant_mid512_codes(G):
     g = load_golden("g3_mid512")
     lin, gp = _run_gptq(G, torch.from_numpy(g["W"]).float(), torch.from_numpy(g["H"]), 2, bits=4, sym=False)
