@@ -187,6 +187,34 @@ __host__ __device__ constexpr PairSlot pair4(int t) {
   return PairSlot{8 * word + k, 8 * word + k + 4, 6, 6, 32 * word + 4 * k - 6};
 }
 template <int BITS> __host__ __device__ constexpr PairSlot pair_slot(int t) { return BITS == 3 ? pair3(t) : pair4(t); }
+// the same table computed per lane while x is staged (a select cascade over the 16 constexpr entries costs ~100 vector
+// instructions per wave, 15 % of the kernel): codes and bit positions only, checked against the table at compile time
+template <int BITS> __host__ __device__ constexpr PairSlot pair_slot_rt(int t) {
+  if (BITS == 3) {
+    const bool c = t >= 10;
+    const int j = t + (t >= 5 ? 5 : 0) + (c ? 5 : 0);
+    return PairSlot{j, j + (c ? 6 : 5), c ? 5 : 7, c ? 7 : 6, 0};
+  }
+  const int j = 8 * (t >> 2) + (t & 3);
+  return PairSlot{j, j + 4, 6, 6, 0};
+}
+template <int BITS> constexpr bool pair_slot_rt_ok() {
+  for (int t = 0; t < 16; ++t) {
+    const PairSlot a = pair_slot<BITS>(t), b = pair_slot_rt<BITS>(t);
+    if (a.jlo != b.jlo || a.jhi != b.jhi || a.plo != b.plo || a.phi != b.phi) return false;
+  }
+  return true;
+}
+static_assert(pair_slot_rt_ok<3>() && pair_slot_rt_ok<4>(), "pair_slot_rt disagrees with the pair table");
+
+// sum over the 16 lanes of a DPP row, result in every lane (row rotations: no LDS round trips)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+  return v;
+}
 
 // the 32-bit window of the group's bit stream that starts at bit s (may start before bit 0 or run past the end: zeros)
 template <int BITS, int S>
@@ -224,7 +252,7 @@ constexpr int MV_PF = 2;
 constexpr int MV2_KG_MAX = 128;
 static inline size_t matvec2_lds_bytes(int kg) { return sizeof(float) * ((size_t)kg * (32 + 32 + 2) + 4 * 257); }
 
-template <int BITS, typename TV, bool GROUPED>
+template <int BITS, typename TV, bool GROUPED, int ABL = 0>   // ABL: timing-only diagnostic builds (results are wrong)
 __global__ __launch_bounds__(256) void matvec2_kernel(const TV* __restrict__ vec, const int32_t* __restrict__ mat,
                                                       float* __restrict__ mul, const float* __restrict__ scales,
                                                       const float* __restrict__ zeros, int ngroups, int width,
@@ -235,7 +263,8 @@ __global__ __launch_bounds__(256) void matvec2_kernel(const TV* __restrict__ vec
   float* Tg = xs + KG * 32;                               // [KG] constant part per group: sum 1024 * 2^-p * x
   float* Sg = Tg + KG;                                    // [KG] sum of x per group (zero-point term)
   float* red = Sg + KG;                                   // [4][257]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: group indices and row bases stay scalar
   const int g0 = blockIdx.y * KG;
   const int ng = min(KG, ngroups - g0);
   const int col = (blockIdx.x * 64 + lane) * 4;
@@ -245,6 +274,7 @@ __global__ __launch_bounds__(256) void matvec2_kernel(const TV* __restrict__ vec
     const int32_t* p = mat + ((long)(g0 + g) * BITS) * width + col;
 #pragma unroll
     for (int r = 0; r < BITS; ++r) {
+      if (ABL == 3) { w[r][0] = w[r][1] = w[r][2] = w[r][3] = (uint32_t)(g + r + lane); continue; }
       const uint4 q = *reinterpret_cast<const uint4*>(p + (long)r * width);
       w[r][0] = q.x; w[r][1] = q.y; w[r][2] = q.z; w[r][3] = q.w;
     }
@@ -261,19 +291,15 @@ __global__ __launch_bounds__(256) void matvec2_kernel(const TV* __restrict__ vec
   __syncthreads();
   {
     const int t = tid & 15;
-    int jlo = 0, jhi = 0, plo = 0, phi = 0;
-#pragma unroll
-    for (int u = 0; u < 16; ++u)
-      if (u == t) { const PairSlot ps = pair_slot<BITS>(u); jlo = ps.jlo; jhi = ps.jhi; plo = ps.plo; phi = ps.phi; }
+    const PairSlot ps = pair_slot_rt<BITS>(t);
+    const int jlo = ps.jlo, jhi = ps.jhi, plo = ps.plo, phi = ps.phi;
     for (int slot = tid; slot < KG * 16; slot += 256) {   // (KG * 16 is a multiple of 16: whole groups per 16 lanes)
       const int g = slot >> 4;
       const float a = ldexpf(xs[g * 32 + jlo], -plo), b = ldexpf(xs[g * 32 + jhi], -phi);   // exact
       XP[2 * slot] = a;
       XP[2 * slot + 1] = b;
-      float tpart = 1024.f * (a + b);
-      float spart = xs[g * 32 + 2 * t] + xs[g * 32 + 2 * t + 1];
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) { tpart += __shfl_xor(tpart, o); spart += __shfl_xor(spart, o); }
+      const float tpart = row16_sum(1024.f * (a + b));
+      const float spart = row16_sum(xs[g * 32 + 2 * t] + xs[g * 32 + 2 * t + 1]);
       if (t == 0) { Tg[g] = tpart; Sg[g] = spart; }
     }
   }
@@ -299,6 +325,7 @@ __global__ __launch_bounds__(256) void matvec2_kernel(const TV* __restrict__ vec
             uint32_t wc[BITS];
 #pragma unroll
             for (int r = 0; r < BITS; ++r) wc[r] = ring[i][r][v];
+            if (ABL == 2) { for (int r = 0; r < BITS; ++r) acc[v] += __builtin_bit_cast(float, wc[r]); continue; }
             dot_pairs<BITS, 0>(wc, XP + g * 32, magic, acc[v]);
           }
           if (GROUPED) {
@@ -325,6 +352,7 @@ __global__ __launch_bounds__(256) void matvec2_kernel(const TV* __restrict__ vec
     } else {
       float sx = 0.f;
       for (int g = 0; g < ng; ++g) sx += Sg[g];
+      if (ABL == 1) { if (blockIdx.y == (unsigned)(c & 127)) mul[c] = scales[c] * q - zeros[c] * sx; return; }
       atomicAdd(&mul[c], scales[c] * q - zeros[c] * sx);
     }
   }
@@ -352,6 +380,17 @@ static int launch_matvec(const void* vec, int vec_dtype, const int32_t* mat, flo
     const dim3 grid2(colblocks, cdiv(ngroups, kg));
     GPTQ_CHECK_ARG(grid2.y <= 65535, "%s: too many input groups", who);
     const size_t lds = matvec2_lds_bytes(kg);
+#ifdef GPTQ_DIAG   // timing-only ablation builds (wrong results): diagnostic library only
+    static const int abl = [] { const char* e = getenv("GPTQ_MV_ABLATE"); return e ? atoi(e) : 0; }();
+    if (abl && BITS == 3 && groupsize == 0 && vec_dtype == GPTQ_F32) {
+      const float* v = static_cast<const float*>(vec);
+      if (abl == 1) matvec2_kernel<3, float, false, 1><<<grid2, 256, lds, s>>>(v, mat, mul, scales, zeros, ngroups, width, 0, kg);
+      else if (abl == 2) matvec2_kernel<3, float, false, 2><<<grid2, 256, lds, s>>>(v, mat, mul, scales, zeros, ngroups, width, 0, kg);
+      else matvec2_kernel<3, float, false, 3><<<grid2, 256, lds, s>>>(v, mat, mul, scales, zeros, ngroups, width, 0, kg);
+      GPTQ_CHECK_LAUNCH(who);
+      return GPTQ_OK;
+    }
+#endif
 #define MV2_LAUNCH(TV)                                                                                             \
   do {                                                                                                             \
     if (groupsize > 0)                                                                                             \
