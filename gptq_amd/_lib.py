@@ -31,6 +31,8 @@ _SIGNATURES = {
     "gptq_quantize_rows": (C.c_int, [_p, _i, _i, _i, _p, _p, _i, _p]),
     "gptq_hinv_workspace_bytes": (_z, [_i]),
     "gptq_hinv_upper": (C.c_int, [_p, _i, _i, _f, _p, _p, _p, _z, _p]),
+    "gptq_rfactor_upper": (C.c_int, [_p, _i, _i, _f, _p, _p, _p, _z, _p]),
+    "gptq_fasterquant_factor_form": (C.c_int, [_i, _i, _i, _i]),
     "gptq_quant_block": (C.c_int, [_p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i, _p, _i, _p, _p, _i, _p, _p, _p]),
     "gptq_fasterquant_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i]),
     "gptq_fasterquant": (C.c_int, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _p, _p, _i, _p, _p, _p, _p,

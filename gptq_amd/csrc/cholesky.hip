@@ -104,8 +104,8 @@ __device__ __forceinline__ void acc_store(const f32x16& acc, float* T, int ld, i
 // The sub-panel below D is then a plain product with D^-1 (MFMA) instead of a per-row substitution.
 // ---------------------------------------------------------------------------------------------
 template <int J>
-__device__ __forceinline__ void factor32_step(f32x16& S, f32x16& M, float* Xd, int ldx, int32_t* info, int col0,
-                                              int lane) {
+__device__ __forceinline__ void factor32_step(f32x16& S, f32x16& M, float* Xd, int ldx, float* Ld, int32_t* info,
+                                              int col0, int lane) {
   constexpr int e = (J & 3) + 4 * (J >> 3);       // register holding row J
   constexpr int h = (J >> 2) & 1;                 // half of the wave holding row J
   const int c = lane & 31;
@@ -119,6 +119,7 @@ __device__ __forceinline__ void factor32_step(f32x16& S, f32x16& M, float* Xd, i
   const float l = (mine && c >= J) ? srow * inv : 0.f;          // column J of L_D, l_J = sqrt(a_JJ)
   const float x = mine ? M[e] * inv : 0.f;                      // row J of L_D^-1 (exact zeros right of the diagonal)
   if (mine) Xd[J * ldx + c] = x;
+  if (mine) Ld[c * 33 + J] = l;                                  // column J of L_D (zeros above the diagonal)
   const float ls = (c > J) ? l : 0.f;
   S = __builtin_amdgcn_mfma_f32_32x32x2f32(-l, l, S, 0, 0, 0);
   M = __builtin_amdgcn_mfma_f32_32x32x2f32(-ls, x, M, 0, 0, 0);
@@ -133,6 +134,7 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
   extern __shared__ __attribute__((aligned(16))) float dsm[];
   float* S = dsm;                       // [128][129]  A_kk (full, mirrored) -> L off-diagonal blocks -> L_kk^-1
   float* Tt = S + 64;                   // [64][LD]    level-2 intermediate, in the dead quadrant S[0:64, 64:128]
+  float* Ld = S + NB * LD;              // [32][33]    factor of the current diagonal 32 x 32 sub-block
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* Ak = A + (long)kb * NB * Cp + (long)kb * NB;
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
       for (int e = 0; e < 16; ++e) M[e] = ((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) == (lane & 31)) ? 1.f : 0.f;
       float* Xd = S + o * LD + o;                               // X_D takes D's place (D lives in registers now)
       const int c0 = kb * NB + o;
-#define FSTEP(J) factor32_step<J>(D, M, Xd, LD, info, c0, lane)
+#define FSTEP(J) factor32_step<J>(D, M, Xd, LD, Ld, info, c0, lane)
       FSTEP(0); FSTEP(1); FSTEP(2); FSTEP(3); FSTEP(4); FSTEP(5); FSTEP(6); FSTEP(7);
       FSTEP(8); FSTEP(9); FSTEP(10); FSTEP(11); FSTEP(12); FSTEP(13); FSTEP(14); FSTEP(15);
       FSTEP(16); FSTEP(17); FSTEP(18); FSTEP(19); FSTEP(20); FSTEP(21); FSTEP(22); FSTEP(23);
@@ -168,6 +170,14 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
     }
     __syncthreads();
     const int nb_rem = 3 - s;                                   // 32-row blocks under the diagonal sub-block
+    // L_kk itself goes back to A (the column loop's far updates multiply with the FACTOR, see gptq_rfactor_upper):
+    // the diagonal sub-block's factor now, by a wave that has nothing to do in (A2); the blocks under it in (A3)
+    if (wave == 7) {
+      for (int idx = lane; idx < 32 * 32; idx += 64) {
+        const int i = idx >> 5, k = idx & 31;
+        if (k <= i) Ak[(long)(o + i) * Cp + o + k] = Ld[i * 33 + k];
+      }
+    }
     if (wave < nb_rem) {                                        // (A2) P_I = A[I, s] * X_D^T, one block per wave
       const int ri = 32 * (s + 1 + wave);
       f32x16 acc;
@@ -188,6 +198,12 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
         acc_load(acc, S + ri * LD + rk, LD, lane);
         lds_mfma32(acc, S + ri * LD + o, LD, S + rk * LD + o, LD, -1.f, lane);
         acc_store(acc, S + ri * LD + rk, LD, lane);
+      }
+      if (wave >= 6) {                                          // L[I, s] of this column of sub-blocks -> A (final since A2)
+        for (int idx = (wave - 6) * 64 + lane; idx < nb_rem * 32 * 32; idx += 128) {
+          const int i = 32 * (s + 1) + (idx >> 5), k = o + (idx & 31);
+          Ak[(long)i * Cp + k] = S[i * LD + k];
+        }
       }
     }
     __syncthreads();
@@ -247,7 +263,7 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
     Xk[(long)i * Cp + k] = (k <= i) ? S[i * LD + k] : 0.f;
   }
 }
-constexpr size_t POTRF_LDS = sizeof(float) * NB * (NB + 1);
+constexpr size_t POTRF_LDS = sizeof(float) * (NB * (NB + 1) + 32 * 33);
 
 
 // Panel:  P <- P * inv(L_kk)^T  for the block column kb below the diagonal (rows (kb+1)*128 ...), IN PLACE.
@@ -368,6 +384,17 @@ __global__ __launch_bounds__(256) void flip_to_upper_kernel(const float* __restr
   U[(long)i * ldu + j] = (j >= i) ? Linv[(long)(C - 1 - i) * Cp + (C - 1 - j)] : 0.f;
 }
 
+// The same flip for gptq_rfactor_upper (C % 128 == 0): inside the diagonal 128-blocks U_kk = R_kk^-1 (from Linv's
+// diagonal blocks), everywhere else R = J L J itself (from A), zero below the diagonal.
+__global__ __launch_bounds__(256) void flip_mixed_kernel(const float* __restrict__ L, const float* __restrict__ Linv,
+                                                         int Cp, int C, float* __restrict__ U, int ldu) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.y;
+  if (j >= C) return;
+  const long src = (long)(C - 1 - i) * Cp + (C - 1 - j);
+  U[(long)i * ldu + j] = (j < i) ? 0.f : ((j / NB == i / NB) ? Linv[src] : L[src]);
+}
+
 }  // namespace gptq
 
 using namespace gptq;
@@ -384,9 +411,8 @@ extern "C" size_t gptq_hinv_workspace_bytes(int C) {
   return cv.used();
 }
 
-extern "C" int gptq_hinv_upper(float* H, int ldh, int C, float percdamp, const int32_t* perm,
-                               int32_t* info, void* workspace, size_t workspace_bytes,
-                               gptq_stream_t stream) {
+static int factor_chain(float* H, int ldh, int C, float percdamp, const int32_t* perm, int32_t* info, void* workspace,
+                        size_t workspace_bytes, gptq_stream_t stream, bool rfactor) {
   GPTQ_CHECK_ARG(H && workspace, "gptq_hinv_upper: null pointer");
   GPTQ_CHECK_ARG(C > 0 && ldh >= C, "gptq_hinv_upper: bad sizes");
   GPTQ_CHECK_ARG(workspace_bytes >= gptq_hinv_workspace_bytes(C), "gptq_hinv_upper: workspace too small");
@@ -440,6 +466,11 @@ extern "C" int gptq_hinv_upper(float* H, int ldh, int C, float percdamp, const i
     }
   }
   if (side_busy) GPTQ_CHECK_HIP(hipStreamWaitEvent(s, sc->side_done, 0));
+  if (rfactor) {                                                 // no triangular inverse: half the chain's flops
+    flip_mixed_kernel<<<dim3(cdiv(C, 256), C), 256, 0, s>>>(A, Linv, Cp, C, H, ldh);
+    GPTQ_CHECK_LAUNCH("gptq_rfactor_upper");
+    return GPTQ_OK;
+  }
   for (int sz = 1; sz < nblk; sz *= 2) {
     const int pairs = cdiv(nblk, 2 * sz);
     trtri_step1_kernel<<<dim3(sz * sz, pairs, 4), GEMM_THREADS, 0, s>>>(A, Linv, Cp, nblk, sz, 0);
@@ -448,4 +479,17 @@ extern "C" int gptq_hinv_upper(float* H, int ldh, int C, float percdamp, const i
   flip_to_upper_kernel<<<dim3(cdiv(C, 256), C), 256, 0, s>>>(Linv, Cp, C, H, ldh);
   GPTQ_CHECK_LAUNCH("gptq_hinv_upper");
   return GPTQ_OK;
+}
+
+extern "C" int gptq_hinv_upper(float* H, int ldh, int C, float percdamp, const int32_t* perm,
+                               int32_t* info, void* workspace, size_t workspace_bytes,
+                               gptq_stream_t stream) {
+  return factor_chain(H, ldh, C, percdamp, perm, info, workspace, workspace_bytes, stream, false);
+}
+
+extern "C" int gptq_rfactor_upper(float* H, int ldh, int C, float percdamp, const int32_t* perm,
+                                  int32_t* info, void* workspace, size_t workspace_bytes,
+                                  gptq_stream_t stream) {
+  GPTQ_CHECK_ARG(C > 0 && C % NB == 0, "gptq_rfactor_upper: C must be a positive multiple of 128");
+  return factor_chain(H, ldh, C, percdamp, perm, info, workspace, workspace_bytes, stream, true);
 }

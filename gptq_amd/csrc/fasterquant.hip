@@ -6,6 +6,8 @@
 // separate multiply and subtract -- this file is compiled with -ffp-contract=off), so identical
 // (W1, Hinv1, scale, zero) give identical bits.  Reductions (the trailing GEMM, the loss sum) are
 // tolerance-level: their summation order differs from MKL's.
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "gemm2_f32.h"
@@ -203,6 +205,8 @@ struct QuantBlockArgs {
   float* Err; uint8_t* codes; int ldc; const int32_t* col_map; float* loss;
   int lde;   // leading dimension of Err (>= blocksize): Err1 of this block is Err[r * lde + 0 .. blocksize)
   int errw;  // = blocksize: Err columns [count, errw) are zeroed (the kernel's own width 32 * NPH may be larger)
+  int nmode; // != 0: Err holds the ORIGINAL weights of the block's columns on entry and receives Q1 - W0 instead of
+             // Err1 (the factor form of the trailing updates, see rform_convert_kernel)
 };
 
 // One 32-column phase PH of the block (compile-time, so every "is there a later group" test and every
@@ -329,7 +333,10 @@ __device__ __forceinline__ void quant_phase(const QuantBlockArgs& a, float (&w)[
         wrow[col] = w[8 * ph + t];
         if (a.codes) a.codes[rbase * a.ldc + cmap[col]] = (uint8_t)cd[t];
       }
-      if (col < a.errw) a.Err[rbase * a.lde + col] = (col < a.count) ? e[t] : 0.f;
+      if (col < a.errw) {
+        float* ep = a.Err + rbase * a.lde + col;
+        *ep = (col < a.count) ? (a.nmode ? w[8 * ph + t] - *ep : e[t]) : 0.f;
+      }
     }
   }
   if (PH + 1 < NPH) stage_store<NPH>(Us_next, tid, nxt);
@@ -412,6 +419,50 @@ __global__ __launch_bounds__(GEMM_THREADS) void trailing128_kernel(float* __rest
                    (lde % 4) == 0 && reinterpret_cast<uintptr_t>(E) % 16 == 0};
   Operand<float> b{U + (long)u0 * ldu + c0, 1, ldu, (int)min((long)GBN, c_end - c0), bvec};
   gemm_tile<float, float, true, false>(a, b, 0, K, smem, Epilogue{W + r0 * ldw + c0, ldw, 1, EPI_SUB, TRI_ALL, 0.f, 0.f});
+}
+
+// ---------------------------------------------------------------------------------------------
+// Factor form of the cross-block compensation (no explicit inverse factor).
+// With x = w0 - q (total change of a row), e = its Err1 values and R = U^-1 (H + damp I = R R^T, R upper: what the
+// reversed Cholesky factorization yields BEFORE any triangular inverse), the reference's updates e U = x sum up to
+//     e = x R      and      W1[:, blk] = W0[:, blk] + (sum_{k < blk} x_k R[k, blk]) U_kk,    U_kk = R_kk^-1,
+// because U[B, blk] = -R_BB^-1 R[B, blk] U_kk for the columns B before the block.  So the trailing updates can run on
+// an accumulator  Acc[:, j] -= (Q1 - W0)[:, blk] R[blk, j]  with the FACTOR's rows, and only the 128 x 128 diagonal
+// blocks of U are ever needed (the diagonal-block kernel of the factorization already forms them).  This kernel turns
+// the accumulator into the block's working weights right before its column loop:
+//     W[:, blk] += Acc[:, blk] U_kk     (the old W, i.e. W0, is parked in X for quant_block_kernel's nmode)
+// and the column loop itself stays the reference's, bit for bit, given (W1, U_kk).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GEMM_THREADS) void rform_convert_kernel(float* __restrict__ W, int ldw, int R, int i1,
+                                                                     int count, const float* __restrict__ Acc, int lda,
+                                                                     const float* __restrict__ U, int ldu,
+                                                                     float* __restrict__ X, int ldx, bool bvec) {
+  __shared__ __attribute__((aligned(16))) float smem[GEMM64_LDS_FLOATS];
+  const int tn = blockIdx.x, tm = blockIdx.y;
+  const long r0 = (long)tm * SBM;
+  const int c0 = tn * SBN;
+  const int rem_m = (int)min((long)SBM, R - r0), rem_n = min(SBN, count - c0);
+  Operand<float> a{Acc + r0 * lda + i1, lda, 1, rem_m, (lda % 4) == 0 && (i1 % 4) == 0 &&
+                                                           reinterpret_cast<uintptr_t>(Acc) % 16 == 0};
+  Operand<float> b{U + (long)i1 * ldu + i1 + c0, 1, ldu, rem_n, bvec};
+  f32x16 acc;
+  gemm_acc64<float, float, true, false>(a, b, 0, min(count, c0 + SBN), smem, acc);   // U_kk is upper: k <= n
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  float old[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int row = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5), col = wn * 32 + (lane & 31);
+    old[e] = (row < rem_m && col < rem_n) ? W[(r0 + row) * ldw + i1 + c0 + col] : 0.f;
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int row = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5), col = wn * 32 + (lane & 31);
+    if (row < rem_m && col < rem_n) {
+      W[(r0 + row) * ldw + i1 + c0 + col] = old[e] + acc[e];
+      X[(r0 + row) * ldx + c0 + col] = old[e];
+    }
+  }
 }
 
 }  // namespace gptq
@@ -509,7 +560,7 @@ extern "C" int gptq_quant_block(float* W, int ldw, int R, int C, int i1, int cou
   GPTQ_CHECK_ARG(ldw >= C && ldu >= C && tab_ld >= 1, "gptq_quant_block: bad leading dimension");
   GPTQ_CHECK_ARG(bits >= 1 && bits <= 8, "gptq_quant_block: bits must be in 1..8");
   QuantBlockArgs a{W, ldw, R, i1, count, U, ldu, scale_tab, zero_tab, tab_ld, col_group,
-                   (float)((1 << bits) - 1), Err, codes, ldc, col_map, loss, blocksize, blocksize};
+                   (float)((1 << bits) - 1), Err, codes, ldc, col_map, loss, blocksize, blocksize, 0};
   return launch_quant_block(a, blocksize, col_group != nullptr, static_cast<hipStream_t>(stream));
 }
 
@@ -522,14 +573,26 @@ namespace {
 // BLAS regroups them too).
 constexpr int SUPER = 4;
 struct SolveWs {
-  float* Wp; float* Err; float* loss; float* diag; float* stab; float* ztab;
+  float* Wp; float* Acc; float* Err; float* loss; float* diag; float* stab; float* ztab;
   int32_t* dead; int32_t* perm; int32_t* cgroup; void* hinv; size_t hinv_bytes; size_t total;
 };
-SolveWs carve_solve(void* base, int R, int C, int blocksize, int groupsize, int actorder) {
+// Factor form (rform_convert_kernel): needs the 128-blocks of the column loop and of the factorization to coincide and
+// every dynamic group inside one block (its grid is taken from the block's converted working weights).
+// It trades the triangular inverse (C^3 / 3 flop) for one small product per block on the critical path: measured
+// break-even near C = 5000 (4096 x 4096: 5.3 -> 5.6 ms; 4096 x 11008: 23.9 -> 20.5; 4096 x 16384: 50.6 -> 39.2), so it is
+// taken from C = 6144 on (GPTQ_RFORM=1: wherever it applies, 0: never).
+bool use_rform(int C, int blocksize, int groupsize, int static_groups) {
+  static const int mode = [] { const char* e = getenv("GPTQ_RFORM"); return e ? atoi(e) : -1; }();
+  if (mode == 0 || C % 128 != 0 || blocksize != 128) return false;
+  if (groupsize > 0 && !static_groups && 128 % groupsize != 0) return false;
+  return mode == 1 || C >= 6144;
+}
+SolveWs carve_solve(void* base, int R, int C, int blocksize, int groupsize, int actorder, int static_groups) {
   Carver cv(base);
   SolveWs w{};
   const int G = groupsize > 0 ? cdiv(C, groupsize) : 1;
   w.Wp = actorder ? cv.take<float>((size_t)R * C) : nullptr;
+  w.Acc = use_rform(C, blocksize, groupsize, static_groups) ? cv.take<float>((size_t)R * C) : nullptr;
   w.Err = cv.take<float>((size_t)2 * R * SUPER * blocksize);   // Err1 of a whole super-block, double buffered
   w.loss = cv.take<float>(R);
   w.diag = cv.take<float>(C);
@@ -545,11 +608,14 @@ SolveWs carve_solve(void* base, int R, int C, int blocksize, int groupsize, int 
 }
 }  // namespace
 
+extern "C" int gptq_fasterquant_factor_form(int C, int blocksize, int groupsize, int static_groups) {
+  return use_rform(C, blocksize, groupsize, static_groups) ? 1 : 0;
+}
+
 extern "C" size_t gptq_fasterquant_workspace_bytes(int R, int C, int blocksize, int groupsize,
                                                    int actorder, int static_groups) {
-  (void)static_groups;
   if (R <= 0 || C <= 0 || blocksize <= 0) return 0;
-  return carve_solve(nullptr, R, C, blocksize, groupsize, actorder).total;
+  return carve_solve(nullptr, R, C, blocksize, groupsize, actorder, static_groups).total;
 }
 
 extern "C" int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R, int C, int bits, int sym,
@@ -571,7 +637,8 @@ extern "C" int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R
   GPTQ_CHECK_ARG(workspace_bytes >= gptq_fasterquant_workspace_bytes(R, C, blocksize, groupsize, actorder, static_groups),
                  "gptq_fasterquant: workspace too small");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const SolveWs ws = carve_solve(workspace, R, C, blocksize, groupsize, actorder);
+  const SolveWs ws = carve_solve(workspace, R, C, blocksize, groupsize, actorder, static_groups);
+  const bool rform = ws.Acc != nullptr;
   const bool grouped = groupsize > 0;
   const bool use_static = static_groups && grouped;   // range(0, C, -1) is empty (gptq.py:159)
   const int G = grouped ? cdiv(C, groupsize) : 1;
@@ -619,10 +686,12 @@ extern "C" int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R
   } else {
     col_group_kernel<<<cdiv(C, TB), TB, 0, ps>>>(ws.cgroup, C, use_static ? perm : nullptr, groupsize);
   }
+  if (rform) GPTQ_CHECK_HIP(hipMemsetAsync(ws.Acc, 0, sizeof(float) * (size_t)R * C, ps));
   if (sc) GPTQ_CHECK_HIP(hipEventRecord(sc->prep_done, sc->stream));
-  // damped inverse factor (gptq.py:174-180): H <- U
+  // damped inverse factor (gptq.py:174-180): H <- U, or (factor form) H <- R = U^-1 with U_kk in the diagonal 128-blocks
   {
-    const int rc = gptq_hinv_upper(H, ldh, C, percdamp, perm, info, ws.hinv, ws.hinv_bytes, stream);
+    const int rc = rform ? gptq_rfactor_upper(H, ldh, C, percdamp, perm, info, ws.hinv, ws.hinv_bytes, stream)
+                         : gptq_hinv_upper(H, ldh, C, percdamp, perm, info, ws.hinv, ws.hinv_bytes, stream);
     if (rc != GPTQ_OK) return rc;
   }
   if (sc) GPTQ_CHECK_HIP(hipStreamWaitEvent(s, sc->prep_done, 0));
@@ -637,6 +706,8 @@ extern "C" int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R
   // column loop needs them next) and "everything beyond" (helper stream, underneath the next super-block's loop).
   bool side_busy = false;
   int sblk = 0;
+  float* Tk = rform ? ws.Acc : Wk;                                   // what the trailing updates write
+  const int ldt = rform ? C : ldk;
   for (int s0 = 0; s0 < C; s0 += SB, ++sblk) {
     const int s1 = std::min(s0 + SB, C);
     float* ErrS = ws.Err + (size_t)(sblk & 1) * R * SUPER * blocksize;   // [R, SB]: block b of the super-block at column b * blocksize
@@ -644,6 +715,9 @@ extern "C" int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R
       const int i2 = std::min(i1 + blocksize, s1);
       const int count = i2 - i1;
       float* Err = ErrS + (i1 - s0);
+      if (rform)                                                     // working weights of this block from the accumulator
+        rform_convert_kernel<<<dim3(cdiv(count, SBN), cdiv(R, SBM)), GEMM_THREADS, 0, s>>>(
+            Wk, ldk, R, i1, count, ws.Acc, C, H, ldh, Err, SB, bvec_base && (i1 % 4 == 0));
       if (grouped && !use_static) {
         // dynamic groups starting inside this block read the CURRENT global W (gptq.py:253-255)
         const int first = cdiv(i1, groupsize) * groupsize;
@@ -659,12 +733,12 @@ extern "C" int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R
         }
       }
       QuantBlockArgs a{Wk, ldk, R, i1, count, H, ldh, ws.stab, ws.ztab, G,
-                       grouped ? ws.cgroup : nullptr, maxq, Err, codes, C, perm, ws.loss, SB, blocksize};
+                       grouped ? ws.cgroup : nullptr, maxq, Err, codes, C, perm, ws.loss, SB, blocksize, rform ? 1 : 0};
       const int rc = launch_quant_block(a, blocksize, grouped, s);
       if (rc != GPTQ_OK) return rc;
       if (i2 < s1)                                                   // the rest of this super-block: rank-blocksize
         trailing_kernel<<<dim3(cdiv(s1 - i2, SBN), cdiv(R, SBM)), GEMM_THREADS, 0, s>>>(
-            Wk, ldk, R, i2, s1, Err, SB, count, H, ldh, i1, bvec_base && (i2 % 4 == 0));
+            Tk, ldt, R, i2, s1, Err, SB, count, H, ldh, i1, bvec_base && (i2 % 4 == 0));
     }
     if (s1 < C) {                                                    // everything beyond: rank-(s1 - s0)
       if (side_busy) {                                               // the previous far update wrote these columns too
@@ -674,7 +748,7 @@ extern "C" int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R
       const bool bvec = bvec_base && (s1 % 4 == 0);
       const int next_end = std::min(C, s1 + SB);
       trailing_kernel<<<dim3(cdiv(next_end - s1, SBN), cdiv(R, SBM)), GEMM_THREADS, 0, s>>>(
-          Wk, ldk, R, s1, next_end, ErrS, SB, s1 - s0, H, ldh, s0, bvec);
+          Tk, ldt, R, s1, next_end, ErrS, SB, s1 - s0, H, ldh, s0, bvec);
       if (next_end < C) {
         hipStream_t ts = s;
         if (sc) {
@@ -683,7 +757,7 @@ extern "C" int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R
           ts = sc->stream;
         }
         trailing128_kernel<<<dim3(cdiv(C - next_end, GBN), cdiv(R, GBM)), GEMM_THREADS, 0, ts>>>(
-            Wk, ldk, R, next_end, C, ErrS, SB, s1 - s0, H, ldh, s0, bvec_base && (next_end % 4 == 0));
+            Tk, ldt, R, next_end, C, ErrS, SB, s1 - s0, H, ldh, s0, bvec_base && (next_end % 4 == 0));
         if (sc) {
           GPTQ_CHECK_HIP(hipEventRecord(sc->side_done, sc->stream));
           side_busy = true;

@@ -309,7 +309,7 @@ def fasterquant_many(solvers, blocksize=128, percdamp=.01, groupsize=-1, actorde
 
 def _enqueue_rows(dev, W, H, quantizer, preset_grid, blocksize, percdamp, groupsize, actorder, static_groups):
     """Enqueue one gptq_fasterquant_rows call on the CURRENT stream for the rows of `W` [R, C] (fp32, contiguous) with
-    the Hessian `H` (consumed: left holding U); nothing here waits for the GPU.  `preset_grid` = (scale, zero) of a
+    the Hessian `H` (consumed: left holding the factor, see `Hinv_form`); nothing here waits for the GPU.  `preset_grid` = (scale, zero) of a
     ready quantizer (gptq.py:181) or None.  Returns the buffers of the call."""
     q = quantizer
     tick = time.time()
@@ -338,8 +338,10 @@ def _enqueue_rows(dev, W, H, quantizer, preset_grid, blocksize, percdamp, groups
                   int(bool(static_groups)), _lib.ptr(scale), _lib.ptr(zero), int(preset_grid is not None),
                   _lib.ptr(gscale), _lib.ptr(gzero), _lib.ptr(perm), _lib.ptr(codes), _lib.ptr(stat),
                   _lib.ptr(row_loss), _lib.ptr(info), _lib.ptr(ws), nbytes, _lib.stream(dev))
+    form = lib.gptq_fasterquant_factor_form(C, int(blocksize), int(groupsize), int(bool(static_groups)))
     return dict(tick=tick, W=W, H=H, scale=scale, zero=zero, gscale=gscale, gzero=gzero, perm=perm, codes=codes,
-                stat=stat, ws=ws, row_loss=row_loss, static_groups=bool(static_groups))
+                stat=stat, ws=ws, row_loss=row_loss, static_groups=bool(static_groups),
+                factor_form="rfactor" if form else "hinv")
 
 
 def _check_solved(st):
@@ -363,7 +365,8 @@ def _publish_rows(obj, st, a, b, error):
     q.maxq = q.maxq.to(obj.dev)
     q.scale = st["scale"][a:b].reshape(-1, 1)
     q.zero = st["zero"][a:b].reshape(-1, 1)
-    obj.Hinv = st["H"]
+    obj.Hinv = st["H"]                   # what the solver left in H: U ("hinv") or R = U^-1 with U's diagonal
+    obj.Hinv_form = st["factor_form"]    # 128-blocks ("rfactor", include/gptq_hip.h: gptq_rfactor_upper)
     obj.codes = st["codes"][a:b]
     obj.group_scale = st["gscale"][a:b] if st["gscale"] is not None else None
     obj.group_zero = st["gzero"][a:b] if st["gzero"] is not None else None

@@ -109,6 +109,22 @@ int gptq_hinv_upper(float* H, int ldh, int C, float percdamp, const int32_t* per
                     void* workspace, size_t workspace_bytes, gptq_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * The same chain WITHOUT the triangular inverse (half its flops), for the factor
+ * form of the column loop's trailing updates (gptq_fasterquant uses it whenever
+ * C % 128 == 0, blocksize == 128 and every dynamic group lies inside one block).
+ * Same arguments as gptq_hinv_upper; C must be a multiple of 128.
+ * Out: H holds, above and on the diagonal, R = U^-1 (H + damp I = R R^T, R upper
+ * triangular) EXCEPT inside the diagonal 128 x 128 blocks, which hold
+ * U_kk = R_kk^-1 (the block of U the in-block loop of gptq.py:201-271 reads);
+ * zero below the diagonal.  Workspace: gptq_hinv_workspace_bytes(C).
+ * ------------------------------------------------------------------------- */
+/* 1 if gptq_fasterquant with these parameters takes the factor form (H is left as gptq_rfactor_upper leaves it),
+ * 0 if it takes the inverse form (H is left holding U). */
+int gptq_fasterquant_factor_form(int C, int blocksize, int groupsize, int static_groups);
+int gptq_rfactor_upper(float* H, int ldh, int C, float percdamp, const int32_t* perm, int32_t* info,
+                       void* workspace, size_t workspace_bytes, gptq_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * One lazy-batch block of the column loop -- replaces gptq.py:195-274 for a
  * single block [i1, i1+count) with the plain affine quantizer (gptq.py:251-264).
  * W [R, C] fp32 working weights: columns [i1, i1+count) are replaced by the
@@ -129,7 +145,8 @@ int gptq_quant_block(float* W, int ldw, int R, int C, int i1, int count, int blo
  * Whole solve -- replaces GPTQ.fasterquant (gptq.py:126-305), default branch.
  * W [R, C] fp32: in = layer weights (original column order), out = dequantized
  * Q in original column order (gptq.py:300-305).  H [C, C] fp32 (upper triangle
- * valid) is consumed and left holding the upper factor U (permuted order).
+ * valid) is consumed and left holding the upper factor U (permuted order) -- or,
+ * where the factor form applies (see gptq_rfactor_upper), what that call leaves.
  * scale_io/zero_io [R]: if preset != 0 they hold a ready grid (gptq.py:181);
  * on return they hold the grid left in the quantizer (last one used).
  * group_scale/group_zero (nullable, [R, n_groups]) receive the per-group grids

@@ -155,7 +155,7 @@ def test_out_of_scope_options_raise(G, hip_device):
 
 
 # ------------------------------------------------------------ chain (tolerance)
-def _hinv_gpu(H, percdamp, perm=None):
+def _hinv_gpu(H, percdamp, perm=None, entry="gptq_hinv_upper"):
     from gptq_amd import _lib
     lib = _lib.load()
     C = H.shape[0]
@@ -164,7 +164,7 @@ def _hinv_gpu(H, percdamp, perm=None):
     ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
     info = torch.zeros(1, dtype=torch.int32, device="cuda")
     p = perm.to(torch.int32).cuda() if perm is not None else None
-    _lib.call("gptq_hinv_upper", _lib.ptr(Hg), Hg.stride(0), C, float(percdamp), _lib.ptr(p), _lib.ptr(info),
+    _lib.call(entry, _lib.ptr(Hg), Hg.stride(0), C, float(percdamp), _lib.ptr(p), _lib.ptr(info),
               _lib.ptr(ws), nb, _lib.stream(Hg.device))
     return Hg.cpu(), int(info.item())
 
@@ -200,6 +200,32 @@ def test_hinv_upper_mid_size_fp64(G):
     Hd = H.double() + torch.eye(C, dtype=torch.float64) * 0.01 * torch.diag(H.double()).mean()
     truth = torch.linalg.cholesky(torch.linalg.inv(Hd), upper=True)
     assert relfro(U, truth) <= 1e-5
+
+
+@pytest.mark.parametrize("C,actorder", [(256, False), (1024, True), (1408, False)])
+def test_rfactor_upper_fp64(G, C, actorder):
+    """The chain without the triangular inverse (include/gptq_hip.h: gptq_rfactor_upper): outside the diagonal
+    128-blocks R with R R^T = H + damp I (R upper = the inverse of the reference's Hinv factor, gptq.py:177-180), inside
+    them the blocks of U = R^-1 -- against fp64, to the tolerance of the inverse-form chain."""
+    gen = torch.Generator().manual_seed(C)
+    X = torch.randn(3 * C, C, generator=gen, dtype=torch.float64) * (1 + torch.arange(C) % 7)
+    H = (X.t() @ X * (2 / (3 * C))).float()
+    perm = torch.argsort(torch.diag(H), descending=True) if actorder else None
+    M, info = _hinv_gpu(H, 0.01, perm, entry="gptq_rfactor_upper")
+    assert info == 0 and torch.equal(M, torch.triu(M))
+    Hd = H.double()
+    if perm is not None:
+        Hd = Hd[perm][:, perm]
+    Hd = Hd + torch.eye(C, dtype=torch.float64) * 0.01 * torch.diag(Hd).mean()
+    U = torch.linalg.cholesky(torch.linalg.inv(Hd), upper=True)
+    Rt = torch.linalg.inv(U)
+    same_blk = (torch.arange(C)[:, None] // 128) == (torch.arange(C)[None, :] // 128)
+    assert relfro(torch.where(same_blk, torch.zeros_like(M), M), torch.where(same_blk, torch.zeros_like(Rt), Rt)) <= 1e-5
+    assert relfro(torch.where(same_blk, M, torch.zeros_like(M)), torch.where(same_blk, U, torch.zeros_like(U))) <= 1e-5
+    # the other entry refuses what it cannot do
+    from gptq_amd import _lib
+    with pytest.raises(_lib.GptqHipError):
+        _hinv_gpu(H[:200, :200].contiguous(), 0.01, entry="gptq_rfactor_upper")
 
 
 def test_hinv_not_positive_definite_raises(G, hip_device):
@@ -739,7 +765,7 @@ def test_full_size_properties_opt1p3b_fc1(G, hip_device):
     Qgrid = gs[:, grp] * (codes.float() - gz[:, grp])
     assert torch.equal(lin.weight.data, Qgrid.half())
     # U^T U (H + damp I) = I  in fp64
-    U = gp.Hinv.double()
+    U = _upper_factor(gp)
     Hd = H.double() + torch.eye(C, device=hip_device, dtype=torch.float64) * 0.01 * torch.diag(H.double()).mean()
     resid = (U.t() @ U @ Hd - torch.eye(C, device=hip_device, dtype=torch.float64)).norm() / math.sqrt(C)
     assert float(resid) <= 1e-4
@@ -803,8 +829,7 @@ def _full_size_checks(G, W, lin, gp, H, bits, actorder, n_rtn_note=""):
         assert bool((d[:-1] >= d[1:]).all())                                            # descending diag (gptq.py:166)
         Hd = Hd[perm][:, perm]
     # U^T U (H + damp I) = I in fp64
-    U = gp.Hinv.double()
-    assert torch.equal(gp.Hinv, torch.triu(gp.Hinv))
+    U = _upper_factor(gp)
     Hd = Hd + torch.eye(C, device=dev, dtype=torch.float64) * 0.01 * torch.diag(H.double()).mean()
     resid = (U.t() @ (U @ Hd) - torch.eye(C, device=dev, dtype=torch.float64)).norm() / math.sqrt(C)
     del U, Hd
@@ -817,6 +842,25 @@ def _full_size_checks(G, W, lin, gp, H, bits, actorder, n_rtn_note=""):
         return float(((D @ H.double()) * D).sum())
     p_gptq, p_rtn = proxy(lin.weight.data), proxy(rtn)
     return float(resid), p_gptq, p_rtn
+
+
+def _upper_factor(gp):
+    """U (fp64) with U^T U = (H + damp I)^-1 from what the solve left behind: U itself, or (factor form,
+    include/gptq_hip.h: gptq_rfactor_upper) R = U^-1 with U's own diagonal 128-blocks -- then U = R^-1 in fp64 and the
+    stored diagonal blocks must agree with it."""
+    M = gp.Hinv.double()
+    assert torch.equal(gp.Hinv, torch.triu(gp.Hinv))
+    if getattr(gp, "Hinv_form", "hinv") == "hinv":
+        return M
+    C = M.shape[0]
+    Rm = M.clone()
+    for k in range(0, C, 128):
+        blk = M[k:k + 128, k:k + 128]
+        Rm[k:k + 128, k:k + 128] = torch.linalg.solve_triangular(blk, torch.eye(128, device=M.device, dtype=M.dtype), upper=True)
+    U = torch.linalg.solve_triangular(Rm, torch.eye(C, device=M.device, dtype=M.dtype), upper=True)
+    for k in range(0, C, max(128, C // 8 // 128 * 128)):
+        assert relfro(U[k:k + 128, k:k + 128], M[k:k + 128, k:k + 128]) <= 1e-5
+    return U
 
 
 def _calibrated(G, W, n_samples, seed, bits):
