@@ -115,7 +115,7 @@ def parse():
 class Block:
     """One workload instance on this rank: weights + calibration inputs resident in HBM, and the step."""
 
-    def __init__(self, name, args, dev, rank, world, group=None):
+    def __init__(self, name, args, dev, rank, world, group=None, dist_on=False):
         import gptq_amd
         import gptq_amd.gptq as gmod
         self.G, self.gmod = gptq_amd, gmod
@@ -125,6 +125,7 @@ class Block:
         if args.groupsize:
             self.wl["groupsize"] = args.groupsize
         self.name, self.args, self.dev, self.rank, self.world, self.group = name, args, dev, rank, world, group
+        self.dist_on = dist_on or world > 1
         self.groups = self.wl["groups"]
         self.params = sum(r * c for g in self.groups for (_, r, c, _) in g)
         # data-parallel over the calibration samples: rank r holds samples r, r + world, ...
@@ -172,14 +173,14 @@ class Block:
             for j in range(self.local_samples):
                 for s, lin in zip(solvers, g):
                     s.add_batch(self.act_of(gi, lin)[j:j + 1], None)
-            if not gmod.LAZY_HESSIANS or self.world > 1:
+            if not gmod.LAZY_HESSIANS or self.dist_on:
                 gmod.flush_pending()
             e1.record()
             gmod.FLUSH_EVENTS = None
             # 2. solve (opt.py:189-214)
             kw = dict(blocksize=128, percdamp=0.01, groupsize=wl["groupsize"], actorder=wl["actorder"],
                       static_groups=wl["static_groups"])
-            if self.world > 1:
+            if self.dist_on:
                 from gptq_amd import parallel as par
                 packed = par.fasterquant_sharded(solvers, bits=wl["bits"], group=self.group, timings=self.phase_ms if record else None, **kw)
                 e2.record()
@@ -268,8 +269,14 @@ def main():
     # (ranks then share devices and the exchanges are staged through host memory)
     backend = os.environ.get("GPTQ_BENCH_BACKEND", "nccl")
     dev = torch.device("cuda", local_rank % max(ndev, 1))
-    if world > 1:
+    # GPTQ_BENCH_FORCE_DIST=1: take the N > 1 code path (process group, all-reduce of H, all-gather of packed rows) with
+    # whatever world size there is -- with ONE rank this rehearses the RCCL calls on a 1-GPU box
+    dist_on = world > 1 or os.environ.get("GPTQ_BENCH_FORCE_DIST") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -286,15 +293,15 @@ def main():
     gmod.SHARE_INPUT_HESSIANS = not args.no_shared_inputs
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
-    blk = Block(args.workload, args, dev, rank, world)
+    blk = Block(args.workload, args, dev, rank, world, dist_on=dist_on)
     if rank == 0:
         log(f"{args.workload}: inputs resident ({blk.local_samples} samples on this rank); warmup {args.warmup}, steps {args.steps}")
     elapsed = blk.run(args.warmup, args.steps, barrier)
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -367,7 +374,7 @@ def main():
         sys.stdout.flush()
         with os.fdopen(json_fd, "w") as real_stdout:
             real_stdout.write(json.dumps(out) + "\n")
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 
