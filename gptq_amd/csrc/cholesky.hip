@@ -384,15 +384,31 @@ __global__ __launch_bounds__(256) void flip_to_upper_kernel(const float* __restr
   U[(long)i * ldu + j] = (j >= i) ? Linv[(long)(C - 1 - i) * Cp + (C - 1 - j)] : 0.f;
 }
 
-// The same flip for gptq_rfactor_upper (C % 128 == 0): inside the diagonal 128-blocks U_kk = R_kk^-1 (from Linv's
-// diagonal blocks), everywhere else R = J L J itself (from A), zero below the diagonal.
-__global__ __launch_bounds__(256) void flip_mixed_kernel(const float* __restrict__ L, const float* __restrict__ Linv,
-                                                         int Cp, int C, float* __restrict__ U, int ldu) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  const int i = blockIdx.y;
-  if (j >= C) return;
-  const long src = (long)(C - 1 - i) * Cp + (C - 1 - j);
-  U[(long)i * ldu + j] = (j < i) ? 0.f : ((j / NB == i / NB) ? Linv[src] : L[src]);
+// gptq_rfactor_upper's output (C % 128 == 0; L-space block (tm, tk), tm > tk, maps to U-space block
+// (nblk-1-tm, nblk-1-tk), element (r, c) to (C-1-r, C-1-c)):
+//   * off-diagonal blocks: Rt[B, blk] = R[B, blk] * U_blk,blk  with R = J L J and U_kk = R_kk^-1 = J L_kk^-1 J, i.e.
+//     the flipped product L[tm, tk] * L_kk^-1 -- one 64 x 64 tile per workgroup, stored through negative strides;
+//   * diagonal blocks: U_kk (flipped L_kk^-1), zero under their diagonals.
+__global__ __launch_bounds__(GEMM_THREADS) void rtilde_kernel(const float* __restrict__ L,
+                                                              const float* __restrict__ Linv, int Cp, int nblk, int C,
+                                                              float* __restrict__ H, int ldh) {
+  __shared__ __attribute__((aligned(16))) float smem[GEMM64_LDS_FLOATS];
+  int rest = blockIdx.x, tk = 0;                 // strictly lower block (tm, tk), column by column
+  while (rest >= nblk - 1 - tk) { rest -= nblk - 1 - tk; ++tk; }
+  const int tm = tk + 1 + rest;
+  const int sm = blockIdx.y >> 1, sn = blockIdx.y & 1;
+  const long r0 = (long)tm * NB + 64 * sm, kb = (long)tk * NB, c0 = kb + 64 * sn;
+  Operand<float> a{L + r0 * Cp + kb, Cp, 1, 64, true};            // L[r0 + m][kb + k]
+  Operand<float> b{Linv + kb * Cp + c0, 1, Cp, 64, true};         // Linv_kk[k][n], lower: k >= n
+  float* Ht = H + (long)(C - 1 - r0) * ldh + (C - 1 - c0);
+  gemm_tile64<float, float, true, false>(a, b, 64 * sn, NB, smem, Epilogue{Ht, -ldh, -1, EPI_STORE, TRI_ALL, 0.f, 0.f});
+}
+__global__ __launch_bounds__(256) void flip_diag_kernel(const float* __restrict__ Linv, int Cp, int C,
+                                                        float* __restrict__ H, int ldh) {
+  const int i = blockIdx.x * 2 + (threadIdx.x >> 7);             // U-space row
+  const int j = (i / NB) * NB + (threadIdx.x & 127);             // the columns of its diagonal block
+  if (i >= C) return;
+  H[(long)i * ldh + j] = (j < i) ? 0.f : Linv[(long)(C - 1 - i) * Cp + (C - 1 - j)];
 }
 
 }  // namespace gptq
@@ -467,7 +483,9 @@ static int factor_chain(float* H, int ldh, int C, float percdamp, const int32_t*
   }
   if (side_busy) GPTQ_CHECK_HIP(hipStreamWaitEvent(s, sc->side_done, 0));
   if (rfactor) {                                                 // no triangular inverse: half the chain's flops
-    flip_mixed_kernel<<<dim3(cdiv(C, 256), C), 256, 0, s>>>(A, Linv, Cp, C, H, ldh);
+    if (nblk > 1)
+      rtilde_kernel<<<dim3(nblk * (nblk - 1) / 2, 4), GEMM_THREADS, 0, s>>>(A, Linv, Cp, nblk, C, H, ldh);
+    flip_diag_kernel<<<cdiv(C, 2), 256, 0, s>>>(Linv, Cp, C, H, ldh);
     GPTQ_CHECK_LAUNCH("gptq_rfactor_upper");
     return GPTQ_OK;
   }

@@ -137,7 +137,9 @@ __global__ __launch_bounds__(256) void sum_kernel(const float* __restrict__ x, i
 __global__ __launch_bounds__(256) void find_params_kernel(const float* __restrict__ W, int ldw, int R,
                                                           int c0, int c1, int gsize, float maxq, int sym,
                                                           float* __restrict__ scale, float* __restrict__ zero,
-                                                          int tab_ld, int g0) {
+                                                          int tab_ld, int g0, const float* __restrict__ add = nullptr,
+                                                          int lda = 0) {
+  // `add` (nullable): the values are W + add (factor form of the solve: original weights + accumulated compensation)
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int j = blockIdx.y;
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(256) void find_params_kernel(const float* __restric
   const float* w = W + (long)r * ldw;
   float mn = INFINITY, mx = -INFINITY;
   for (int c = lo + lane; c < hi; c += 64) {
-    const float v = w[c];
+    const float v = add ? w[c] + add[(long)r * lda + c] : w[c];
     mn = fminf(mn, v);
     mx = fmaxf(mx, v);
   }
@@ -205,8 +207,8 @@ struct QuantBlockArgs {
   float* Err; uint8_t* codes; int ldc; const int32_t* col_map; float* loss;
   int lde;   // leading dimension of Err (>= blocksize): Err1 of this block is Err[r * lde + 0 .. blocksize)
   int errw;  // = blocksize: Err columns [count, errw) are zeroed (the kernel's own width 32 * NPH may be larger)
-  int nmode; // != 0: Err holds the ORIGINAL weights of the block's columns on entry and receives Q1 - W0 instead of
-             // Err1 (the factor form of the trailing updates, see rform_convert_kernel)
+  const float* acc; int lda;   // nullable: the block's working weights are W + acc (factor form of the solve, see
+                               // gptq_fasterquant_rows) and Err receives Q1 - W instead of Err1
 };
 
 // One 32-column phase PH of the block (compile-time, so every "is there a later group" test and every
@@ -329,14 +331,13 @@ __device__ __forceinline__ void quant_phase(const QuantBlockArgs& a, float (&w)[
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const int col = 32 * ph + 4 * t + c;
+      float out = e[t];
+      if (a.acc && col < a.count) out = w[8 * ph + t] - wrow[col];   // factor form: Q1 - W0 (W0 read back before Q1 replaces it)
       if (col < a.count) {
         wrow[col] = w[8 * ph + t];
         if (a.codes) a.codes[rbase * a.ldc + cmap[col]] = (uint8_t)cd[t];
       }
-      if (col < a.errw) {
-        float* ep = a.Err + rbase * a.lde + col;
-        *ep = (col < a.count) ? (a.nmode ? w[8 * ph + t] - *ep : e[t]) : 0.f;
-      }
+      if (col < a.errw) a.Err[rbase * a.lde + col] = (col < a.count) ? out : 0.f;
     }
   }
   if (PH + 1 < NPH) stage_store<NPH>(Us_next, tid, nxt);
@@ -368,6 +369,7 @@ __global__ __launch_bounds__(256) void quant_block_kernel(QuantBlockArgs a) {
   for (int j = 0; j < NREG; ++j) {
     const int col = 4 * j + c;
     w[j] = (active && col < a.count) ? wrow[col] : 0.f;
+    if (a.acc && active && col < a.count) w[j] += a.acc[rbase * a.lda + a.i1 + col];   // W1 = W0 + accumulated compensation
   }
   float sc = 1.f, zr = 0.f;
   if (!GROUPED && active) {
@@ -422,49 +424,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void trailing128_kernel(float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// Factor form of the cross-block compensation (no explicit inverse factor).
+// Factor form of the cross-block compensation (no explicit inverse factor; used by gptq_fasterquant_rows).
 // With x = w0 - q (total change of a row), e = its Err1 values and R = U^-1 (H + damp I = R R^T, R upper: what the
 // reversed Cholesky factorization yields BEFORE any triangular inverse), the reference's updates e U = x sum up to
 //     e = x R      and      W1[:, blk] = W0[:, blk] + (sum_{k < blk} x_k R[k, blk]) U_kk,    U_kk = R_kk^-1,
-// because U[B, blk] = -R_BB^-1 R[B, blk] U_kk for the columns B before the block.  So the trailing updates can run on
-// an accumulator  Acc[:, j] -= (Q1 - W0)[:, blk] R[blk, j]  with the FACTOR's rows, and only the 128 x 128 diagonal
-// blocks of U are ever needed (the diagonal-block kernel of the factorization already forms them).  This kernel turns
-// the accumulator into the block's working weights right before its column loop:
-//     W[:, blk] += Acc[:, blk] U_kk     (the old W, i.e. W0, is parked in X for quant_block_kernel's nmode)
-// and the column loop itself stays the reference's, bit for bit, given (W1, U_kk).
+// because U[B, blk] = -R_BB^-1 R[B, blk] U_kk for the columns B before the block.  So the trailing updates run on an
+// accumulator  Acc[:, j] -= (Q1 - W0)[:, blk] Rt[blk, j]  with the rows of  Rt = R blockdiag(U_kk)  (gptq_rfactor_upper
+// forms it with ONE pass of small products), the working weights of a block are W0 + Acc -- added while
+// quant_block_kernel loads them -- and only the 128 x 128 diagonal blocks of U are ever needed (the factorization's
+// diagonal-block kernel already forms them).  The in-block loop stays the reference's, bit for bit, given (W1, U_kk).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(GEMM_THREADS) void rform_convert_kernel(float* __restrict__ W, int ldw, int R, int i1,
-                                                                     int count, const float* __restrict__ Acc, int lda,
-                                                                     const float* __restrict__ U, int ldu,
-                                                                     float* __restrict__ X, int ldx, bool bvec) {
-  __shared__ __attribute__((aligned(16))) float smem[GEMM64_LDS_FLOATS];
-  const int tn = blockIdx.x, tm = blockIdx.y;
-  const long r0 = (long)tm * SBM;
-  const int c0 = tn * SBN;
-  const int rem_m = (int)min((long)SBM, R - r0), rem_n = min(SBN, count - c0);
-  Operand<float> a{Acc + r0 * lda + i1, lda, 1, rem_m, (lda % 4) == 0 && (i1 % 4) == 0 &&
-                                                           reinterpret_cast<uintptr_t>(Acc) % 16 == 0};
-  Operand<float> b{U + (long)i1 * ldu + i1 + c0, 1, ldu, rem_n, bvec};
-  f32x16 acc;
-  gemm_acc64<float, float, true, false>(a, b, 0, min(count, c0 + SBN), smem, acc);   // U_kk is upper: k <= n
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  float old[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int row = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5), col = wn * 32 + (lane & 31);
-    old[e] = (row < rem_m && col < rem_n) ? W[(r0 + row) * ldw + i1 + c0 + col] : 0.f;
-  }
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int row = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5), col = wn * 32 + (lane & 31);
-    if (row < rem_m && col < rem_n) {
-      W[(r0 + row) * ldw + i1 + c0 + col] = old[e] + acc[e];
-      X[(r0 + row) * ldx + c0 + col] = old[e];
-    }
-  }
-}
-
 }  // namespace gptq
 
 using namespace gptq;
@@ -560,7 +529,7 @@ extern "C" int gptq_quant_block(float* W, int ldw, int R, int C, int i1, int cou
   GPTQ_CHECK_ARG(ldw >= C && ldu >= C && tab_ld >= 1, "gptq_quant_block: bad leading dimension");
   GPTQ_CHECK_ARG(bits >= 1 && bits <= 8, "gptq_quant_block: bits must be in 1..8");
   QuantBlockArgs a{W, ldw, R, i1, count, U, ldu, scale_tab, zero_tab, tab_ld, col_group,
-                   (float)((1 << bits) - 1), Err, codes, ldc, col_map, loss, blocksize, blocksize, 0};
+                   (float)((1 << bits) - 1), Err, codes, ldc, col_map, loss, blocksize, blocksize, nullptr, 0};
   return launch_quant_block(a, blocksize, col_group != nullptr, static_cast<hipStream_t>(stream));
 }
 
@@ -578,14 +547,10 @@ struct SolveWs {
 };
 // Factor form (rform_convert_kernel): needs the 128-blocks of the column loop and of the factorization to coincide and
 // every dynamic group inside one block (its grid is taken from the block's converted working weights).
-// It trades the triangular inverse (C^3 / 3 flop) for one small product per block on the critical path: measured
-// break-even near C = 5000 (4096 x 4096: 5.3 -> 5.6 ms; 4096 x 11008: 23.9 -> 20.5; 4096 x 16384: 50.6 -> 39.2), so it is
-// taken from C = 6144 on (GPTQ_RFORM=1: wherever it applies, 0: never).
 bool use_rform(int C, int blocksize, int groupsize, int static_groups) {
-  static const int mode = [] { const char* e = getenv("GPTQ_RFORM"); return e ? atoi(e) : -1; }();
-  if (mode == 0 || C % 128 != 0 || blocksize != 128) return false;
-  if (groupsize > 0 && !static_groups && 128 % groupsize != 0) return false;
-  return mode == 1 || C >= 6144;
+  static const int off = [] { const char* e = getenv("GPTQ_RFORM"); return e && atoi(e) == 0; }();   // 0: inverse form
+  if (off || C % 128 != 0 || blocksize != 128) return false;
+  return !(groupsize > 0 && !static_groups) || 128 % groupsize == 0;
 }
 SolveWs carve_solve(void* base, int R, int C, int blocksize, int groupsize, int actorder, int static_groups) {
   Carver cv(base);
@@ -715,9 +680,6 @@ extern "C" int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R
       const int i2 = std::min(i1 + blocksize, s1);
       const int count = i2 - i1;
       float* Err = ErrS + (i1 - s0);
-      if (rform)                                                     // working weights of this block from the accumulator
-        rform_convert_kernel<<<dim3(cdiv(count, SBN), cdiv(R, SBM)), GEMM_THREADS, 0, s>>>(
-            Wk, ldk, R, i1, count, ws.Acc, C, H, ldh, Err, SB, bvec_base && (i1 % 4 == 0));
       if (grouped && !use_static) {
         // dynamic groups starting inside this block read the CURRENT global W (gptq.py:253-255)
         const int first = cdiv(i1, groupsize) * groupsize;
@@ -729,11 +691,12 @@ extern "C" int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R
             side_busy = false;
           }
           find_params_kernel<<<dim3(cdiv(R, 4), ngb), 256, 0, s>>>(Wk, ldk, R, first, c1, groupsize, maxq, sym,
-                                                                   ws.stab, ws.ztab, G, first / groupsize);
+                                                                   ws.stab, ws.ztab, G, first / groupsize,
+                                                                   rform ? ws.Acc : nullptr, C);
         }
       }
       QuantBlockArgs a{Wk, ldk, R, i1, count, H, ldh, ws.stab, ws.ztab, G,
-                       grouped ? ws.cgroup : nullptr, maxq, Err, codes, C, perm, ws.loss, SB, blocksize, rform ? 1 : 0};
+                       grouped ? ws.cgroup : nullptr, maxq, Err, codes, C, perm, ws.loss, SB, blocksize, rform ? ws.Acc : nullptr, C};
       const int rc = launch_quant_block(a, blocksize, grouped, s);
       if (rc != GPTQ_OK) return rc;
       if (i2 < s1)                                                   // the rest of this super-block: rank-blocksize

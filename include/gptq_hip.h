@@ -113,10 +113,14 @@ int gptq_hinv_upper(float* H, int ldh, int C, float percdamp, const int32_t* per
  * form of the column loop's trailing updates (gptq_fasterquant uses it whenever
  * C % 128 == 0, blocksize == 128 and every dynamic group lies inside one block).
  * Same arguments as gptq_hinv_upper; C must be a multiple of 128.
- * Out: H holds, above and on the diagonal, R = U^-1 (H + damp I = R R^T, R upper
- * triangular) EXCEPT inside the diagonal 128 x 128 blocks, which hold
- * U_kk = R_kk^-1 (the block of U the in-block loop of gptq.py:201-271 reads);
- * zero below the diagonal.  Workspace: gptq_hinv_workspace_bytes(C).
+ * Out, with R = U^-1 (H + damp I = R R^T, R upper triangular) and 128 x 128 blocks:
+ *   diagonal blocks    U_kk = R_kk^-1 (the block of U the in-block loop of
+ *                      gptq.py:201-271 reads), zero under their diagonals;
+ *   blocks above them  Rt[B, blk] = R[B, blk] * U_blk,blk  (the factor's rows,
+ *                      pre-multiplied so that  W1[:, blk] = W0[:, blk] -
+ *                      sum_B (Q - W0)[:, B] Rt[B, blk]  needs no further product);
+ *   blocks below them  untouched.
+ * Workspace: gptq_hinv_workspace_bytes(C).
  * ------------------------------------------------------------------------- */
 /* 1 if gptq_fasterquant with these parameters takes the factor form (H is left as gptq_rfactor_upper leaves it),
  * 0 if it takes the inverse form (H is left holding U). */

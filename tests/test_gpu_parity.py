@@ -212,16 +212,20 @@ def test_rfactor_upper_fp64(G, C, actorder):
     H = (X.t() @ X * (2 / (3 * C))).float()
     perm = torch.argsort(torch.diag(H), descending=True) if actorder else None
     M, info = _hinv_gpu(H, 0.01, perm, entry="gptq_rfactor_upper")
-    assert info == 0 and torch.equal(M, torch.triu(M))
+    assert info == 0
     Hd = H.double()
     if perm is not None:
         Hd = Hd[perm][:, perm]
     Hd = Hd + torch.eye(C, dtype=torch.float64) * 0.01 * torch.diag(Hd).mean()
     U = torch.linalg.cholesky(torch.linalg.inv(Hd), upper=True)
-    Rt = torch.linalg.inv(U)
-    same_blk = (torch.arange(C)[:, None] // 128) == (torch.arange(C)[None, :] // 128)
-    assert relfro(torch.where(same_blk, torch.zeros_like(M), M), torch.where(same_blk, torch.zeros_like(Rt), Rt)) <= 1e-5
-    assert relfro(torch.where(same_blk, M, torch.zeros_like(M)), torch.where(same_blk, U, torch.zeros_like(U))) <= 1e-5
+    blk = torch.arange(C) // 128
+    same_blk, above = blk[:, None] == blk[None, :], blk[:, None] < blk[None, :]
+    Ud = torch.where(same_blk, U, torch.zeros_like(U))                     # blockdiag(U_kk)
+    Rt = torch.linalg.inv(U) @ Ud                                          # R blockdiag(U_kk)
+    zero = torch.zeros_like(U)
+    assert relfro(torch.where(above, M.double(), zero), torch.where(above, Rt, zero)) <= 1e-5
+    assert relfro(torch.where(same_blk, M.double(), zero), Ud) <= 1e-5
+    assert bool((M[same_blk & (torch.arange(C)[:, None] > torch.arange(C)[None, :])] == 0).all())
     # the other entry refuses what it cannot do
     from gptq_amd import _lib
     with pytest.raises(_lib.GptqHipError):
@@ -846,18 +850,20 @@ def _full_size_checks(G, W, lin, gp, H, bits, actorder, n_rtn_note=""):
 
 def _upper_factor(gp):
     """U (fp64) with U^T U = (H + damp I)^-1 from what the solve left behind: U itself, or (factor form,
-    include/gptq_hip.h: gptq_rfactor_upper) R = U^-1 with U's own diagonal 128-blocks -- then U = R^-1 in fp64 and the
-    stored diagonal blocks must agree with it."""
-    M = gp.Hinv.double()
-    assert torch.equal(gp.Hinv, torch.triu(gp.Hinv))
+    include/gptq_hip.h: gptq_rfactor_upper) R blockdiag(U_kk) above U's own diagonal 128-blocks -- then R is rebuilt and
+    inverted in fp64, and the stored diagonal blocks must agree with that inverse."""
     if getattr(gp, "Hinv_form", "hinv") == "hinv":
-        return M
+        assert torch.equal(gp.Hinv, torch.triu(gp.Hinv))
+        return gp.Hinv.double()
+    M = torch.triu(gp.Hinv.double())          # (the blocks under the diagonal blocks are not part of the result)
     C = M.shape[0]
-    Rm = M.clone()
-    for k in range(0, C, 128):
-        blk = M[k:k + 128, k:k + 128]
-        Rm[k:k + 128, k:k + 128] = torch.linalg.solve_triangular(blk, torch.eye(128, device=M.device, dtype=M.dtype), upper=True)
-    U = torch.linalg.solve_triangular(Rm, torch.eye(C, device=M.device, dtype=M.dtype), upper=True)
+    I128 = torch.eye(128, device=M.device, dtype=M.dtype)
+    for k in range(0, C, 128):                # R[:, blk] = Rt[:, blk] U_kk^-1,  R_kk = U_kk^-1
+        Rkk = torch.linalg.solve_triangular(M[k:k + 128, k:k + 128], I128, upper=True)
+        M[:k, k:k + 128] = M[:k, k:k + 128] @ Rkk
+        M[k:k + 128, k:k + 128] = Rkk
+    U = torch.linalg.solve_triangular(M, torch.eye(C, device=M.device, dtype=M.dtype), upper=True)
+    M = gp.Hinv.double()
     for k in range(0, C, max(128, C // 8 // 128 * 128)):
         assert relfro(U[k:k + 128, k:k + 128], M[k:k + 128, k:k + 128]) <= 1e-5
     return U
