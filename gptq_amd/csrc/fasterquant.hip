@@ -137,9 +137,7 @@ __global__ __launch_bounds__(256) void sum_kernel(const float* __restrict__ x, i
 __global__ __launch_bounds__(256) void find_params_kernel(const float* __restrict__ W, int ldw, int R,
                                                           int c0, int c1, int gsize, float maxq, int sym,
                                                           float* __restrict__ scale, float* __restrict__ zero,
-                                                          int tab_ld, int g0, const float* __restrict__ add = nullptr,
-                                                          int lda = 0) {
-  // `add` (nullable): the values are W + add (factor form of the solve: original weights + accumulated compensation)
+                                                          int tab_ld, int g0) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int j = blockIdx.y;
@@ -148,7 +146,7 @@ __global__ __launch_bounds__(256) void find_params_kernel(const float* __restric
   const float* w = W + (long)r * ldw;
   float mn = INFINITY, mx = -INFINITY;
   for (int c = lo + lane; c < hi; c += 64) {
-    const float v = add ? w[c] + add[(long)r * lda + c] : w[c];
+    const float v = w[c];
     mn = fminf(mn, v);
     mx = fmaxf(mx, v);
   }
@@ -207,8 +205,8 @@ struct QuantBlockArgs {
   float* Err; uint8_t* codes; int ldc; const int32_t* col_map; float* loss;
   int lde;   // leading dimension of Err (>= blocksize): Err1 of this block is Err[r * lde + 0 .. blocksize)
   int errw;  // = blocksize: Err columns [count, errw) are zeroed (the kernel's own width 32 * NPH may be larger)
-  const float* acc; int lda;   // nullable: the block's working weights are W + acc (factor form of the solve, see
-                               // gptq_fasterquant_rows) and Err receives Q1 - W instead of Err1
+  const float* w0; int ldw0;   // nullable: the ORIGINAL weights (same layout as W); Err then receives Q1 - W0 instead of
+                               // Err1 (factor form of the trailing updates, see gptq_fasterquant_rows)
 };
 
 // One 32-column phase PH of the block (compile-time, so every "is there a later group" test and every
@@ -272,6 +270,12 @@ __device__ __forceinline__ void quant_phase(const QuantBlockArgs& a, float (&w)[
       pzr[t] = (active && col < a.count) ? a.zero_tab[rbase * a.tab_ld + g] : 0.f;
     }
   }
+  float w0p[8];                                             // factor form: this phase's original weights, for the retire below
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int col = 32 * ph + 4 * t + c;
+    w0p[t] = (a.w0 && active && col < a.count) ? a.w0[rbase * a.ldw0 + a.i1 + col] : 0.f;
+  }
   const bool tail = !GROUPED && (32 * ph + 32 > a.count);   // block-uniform, false except in a tail block
   // (issued after the grid loads above: vector-memory results return in order)
   float nxt[NST];
@@ -331,8 +335,7 @@ __device__ __forceinline__ void quant_phase(const QuantBlockArgs& a, float (&w)[
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const int col = 32 * ph + 4 * t + c;
-      float out = e[t];
-      if (a.acc && col < a.count) out = w[8 * ph + t] - wrow[col];   // factor form: Q1 - W0 (W0 read back before Q1 replaces it)
+      const float out = a.w0 ? w[8 * ph + t] - w0p[t] : e[t];         // factor form: Q1 - W0
       if (col < a.count) {
         wrow[col] = w[8 * ph + t];
         if (a.codes) a.codes[rbase * a.ldc + cmap[col]] = (uint8_t)cd[t];
@@ -369,7 +372,6 @@ __global__ __launch_bounds__(256) void quant_block_kernel(QuantBlockArgs a) {
   for (int j = 0; j < NREG; ++j) {
     const int col = 4 * j + c;
     w[j] = (active && col < a.count) ? wrow[col] : 0.f;
-    if (a.acc && active && col < a.count) w[j] += a.acc[rbase * a.lda + a.i1 + col];   // W1 = W0 + accumulated compensation
   }
   float sc = 1.f, zr = 0.f;
   if (!GROUPED && active) {
@@ -429,9 +431,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void trailing128_kernel(float* __rest
 // reversed Cholesky factorization yields BEFORE any triangular inverse), the reference's updates e U = x sum up to
 //     e = x R      and      W1[:, blk] = W0[:, blk] + (sum_{k < blk} x_k R[k, blk]) U_kk,    U_kk = R_kk^-1,
 // because U[B, blk] = -R_BB^-1 R[B, blk] U_kk for the columns B before the block.  So the trailing updates run on an
-// accumulator  Acc[:, j] -= (Q1 - W0)[:, blk] Rt[blk, j]  with the rows of  Rt = R blockdiag(U_kk)  (gptq_rfactor_upper
-// forms it with ONE pass of small products), the working weights of a block are W0 + Acc -- added while
-// quant_block_kernel loads them -- and only the 128 x 128 diagonal blocks of U are ever needed (the factorization's
+// working weights in place,  W[:, j] -= (Q1 - W0)[:, blk] Rt[blk, j]  with the rows of  Rt = R blockdiag(U_kk)
+// (gptq_rfactor_upper forms it with ONE pass of small products) -- the inverse form's kernels with other operands: the
+// original weights are kept in a copy, from which quant_block_kernel forms Q1 - W0 when it retires a phase --
+// and only the 128 x 128 diagonal blocks of U are ever needed (the factorization's
 // diagonal-block kernel already forms them).  The in-block loop stays the reference's, bit for bit, given (W1, U_kk).
 // ---------------------------------------------------------------------------------------------
 }  // namespace gptq
@@ -542,11 +545,12 @@ namespace {
 // BLAS regroups them too).
 constexpr int SUPER = 4;
 struct SolveWs {
-  float* Wp; float* Acc; float* Err; float* loss; float* diag; float* stab; float* ztab;
+  float* Wp; float* W0; float* Err; float* loss; float* diag; float* stab; float* ztab;
   int32_t* dead; int32_t* perm; int32_t* cgroup; void* hinv; size_t hinv_bytes; size_t total;
 };
-// Factor form (rform_convert_kernel): needs the 128-blocks of the column loop and of the factorization to coincide and
-// every dynamic group inside one block (its grid is taken from the block's converted working weights).
+// Factor form: needs the 128-blocks of the column loop and of the factorization to coincide, and every dynamic group
+// inside one block (columns of LATER blocks hold partial sums that differ from the inverse form's until all the
+// blocks before them have been applied, and a dynamic group's grid is taken from them, gptq.py:253-255).
 bool use_rform(int C, int blocksize, int groupsize, int static_groups) {
   static const int off = [] { const char* e = getenv("GPTQ_RFORM"); return e && atoi(e) == 0; }();   // 0: inverse form
   if (off || C % 128 != 0 || blocksize != 128) return false;
@@ -557,7 +561,7 @@ SolveWs carve_solve(void* base, int R, int C, int blocksize, int groupsize, int 
   SolveWs w{};
   const int G = groupsize > 0 ? cdiv(C, groupsize) : 1;
   w.Wp = actorder ? cv.take<float>((size_t)R * C) : nullptr;
-  w.Acc = use_rform(C, blocksize, groupsize, static_groups) ? cv.take<float>((size_t)R * C) : nullptr;
+  w.W0 = use_rform(C, blocksize, groupsize, static_groups) ? cv.take<float>((size_t)R * C) : nullptr;
   w.Err = cv.take<float>((size_t)2 * R * SUPER * blocksize);   // Err1 of a whole super-block, double buffered
   w.loss = cv.take<float>(R);
   w.diag = cv.take<float>(C);
@@ -603,7 +607,7 @@ extern "C" int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R
                  "gptq_fasterquant: workspace too small");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const SolveWs ws = carve_solve(workspace, R, C, blocksize, groupsize, actorder, static_groups);
-  const bool rform = ws.Acc != nullptr;
+  const bool rform = ws.W0 != nullptr;
   const bool grouped = groupsize > 0;
   const bool use_static = static_groups && grouped;   // range(0, C, -1) is empty (gptq.py:159)
   const int G = grouped ? cdiv(C, groupsize) : 1;
@@ -651,9 +655,11 @@ extern "C" int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R
   } else {
     col_group_kernel<<<cdiv(C, TB), TB, 0, ps>>>(ws.cgroup, C, use_static ? perm : nullptr, groupsize);
   }
-  if (rform) GPTQ_CHECK_HIP(hipMemsetAsync(ws.Acc, 0, sizeof(float) * (size_t)R * C, ps));
+  if (rform)                                                      // factor form: the original (permuted, dead columns zeroed) weights
+    GPTQ_CHECK_HIP(hipMemcpy2DAsync(ws.W0, sizeof(float) * C, Wk, sizeof(float) * ldk, sizeof(float) * C, R,
+                                    hipMemcpyDeviceToDevice, ps));
   if (sc) GPTQ_CHECK_HIP(hipEventRecord(sc->prep_done, sc->stream));
-  // damped inverse factor (gptq.py:174-180): H <- U, or (factor form) H <- R = U^-1 with U_kk in the diagonal 128-blocks
+  // damped inverse factor (gptq.py:174-180): H <- U, or (factor form) what gptq_rfactor_upper leaves
   {
     const int rc = rform ? gptq_rfactor_upper(H, ldh, C, percdamp, perm, info, ws.hinv, ws.hinv_bytes, stream)
                          : gptq_hinv_upper(H, ldh, C, percdamp, perm, info, ws.hinv, ws.hinv_bytes, stream);
@@ -671,8 +677,6 @@ extern "C" int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R
   // column loop needs them next) and "everything beyond" (helper stream, underneath the next super-block's loop).
   bool side_busy = false;
   int sblk = 0;
-  float* Tk = rform ? ws.Acc : Wk;                                   // what the trailing updates write
-  const int ldt = rform ? C : ldk;
   for (int s0 = 0; s0 < C; s0 += SB, ++sblk) {
     const int s1 = std::min(s0 + SB, C);
     float* ErrS = ws.Err + (size_t)(sblk & 1) * R * SUPER * blocksize;   // [R, SB]: block b of the super-block at column b * blocksize
@@ -691,17 +695,16 @@ extern "C" int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R
             side_busy = false;
           }
           find_params_kernel<<<dim3(cdiv(R, 4), ngb), 256, 0, s>>>(Wk, ldk, R, first, c1, groupsize, maxq, sym,
-                                                                   ws.stab, ws.ztab, G, first / groupsize,
-                                                                   rform ? ws.Acc : nullptr, C);
+                                                                   ws.stab, ws.ztab, G, first / groupsize);
         }
       }
       QuantBlockArgs a{Wk, ldk, R, i1, count, H, ldh, ws.stab, ws.ztab, G,
-                       grouped ? ws.cgroup : nullptr, maxq, Err, codes, C, perm, ws.loss, SB, blocksize, rform ? ws.Acc : nullptr, C};
+                       grouped ? ws.cgroup : nullptr, maxq, Err, codes, C, perm, ws.loss, SB, blocksize, rform ? ws.W0 : nullptr, C};
       const int rc = launch_quant_block(a, blocksize, grouped, s);
       if (rc != GPTQ_OK) return rc;
       if (i2 < s1)                                                   // the rest of this super-block: rank-blocksize
         trailing_kernel<<<dim3(cdiv(s1 - i2, SBN), cdiv(R, SBM)), GEMM_THREADS, 0, s>>>(
-            Tk, ldt, R, i2, s1, Err, SB, count, H, ldh, i1, bvec_base && (i2 % 4 == 0));
+            Wk, ldk, R, i2, s1, Err, SB, count, H, ldh, i1, bvec_base && (i2 % 4 == 0));
     }
     if (s1 < C) {                                                    // everything beyond: rank-(s1 - s0)
       if (side_busy) {                                               // the previous far update wrote these columns too
@@ -711,7 +714,7 @@ extern "C" int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R
       const bool bvec = bvec_base && (s1 % 4 == 0);
       const int next_end = std::min(C, s1 + SB);
       trailing_kernel<<<dim3(cdiv(next_end - s1, SBN), cdiv(R, SBM)), GEMM_THREADS, 0, s>>>(
-          Tk, ldt, R, s1, next_end, ErrS, SB, s1 - s0, H, ldh, s0, bvec);
+          Wk, ldk, R, s1, next_end, ErrS, SB, s1 - s0, H, ldh, s0, bvec);
       if (next_end < C) {
         hipStream_t ts = s;
         if (sc) {
@@ -720,7 +723,7 @@ extern "C" int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R
           ts = sc->stream;
         }
         trailing128_kernel<<<dim3(cdiv(C - next_end, GBN), cdiv(R, GBM)), GEMM_THREADS, 0, ts>>>(
-            Tk, ldt, R, next_end, C, ErrS, SB, s1 - s0, H, ldh, s0, bvec_base && (next_end % 4 == 0));
+            Wk, ldk, R, next_end, C, ErrS, SB, s1 - s0, H, ldh, s0, bvec_base && (next_end % 4 == 0));
         if (sc) {
           GPTQ_CHECK_HIP(hipEventRecord(sc->side_done, sc->stream));
           side_busy = true;
