@@ -58,6 +58,29 @@ __global__ __launch_bounds__(256) void build_abar_kernel(const float* __restrict
   A[(long)i * Cp + j] = v;
 }
 
+// The same with an act-order permutation, from a SYMMETRIC H (both triangles valid): row i of Abar is row
+// perm[C-1-i] of H gathered through perm -- the row goes through LDS with 16-byte reads, the gather happens there
+// (the direct kernel above reads 4 bytes per 64-byte sector: 0.76 ms at C = 11008 against 0.2 ms with the mirror pass).
+__global__ __launch_bounds__(512) void build_abar_perm_kernel(const float* __restrict__ H, int ldh, int C, int Cp,
+                                                              const int32_t* __restrict__ perm,
+                                                              const float* __restrict__ damp, float* __restrict__ A) {
+  extern __shared__ __attribute__((aligned(16))) float rowbuf[];
+  for (int i = blockIdx.x; i < Cp; i += gridDim.x) {
+    float* a = A + (long)i * Cp;
+    if (i >= C) {                                                  // padding: identity
+      for (int j = threadIdx.x; j <= i; j += 512) a[j] = (j == i) ? 1.f : 0.f;
+      continue;
+    }
+    const float* h = H + (long)perm[C - 1 - i] * ldh;
+    for (int p = threadIdx.x * 4; p < C; p += 2048)
+      *reinterpret_cast<float4*>(rowbuf + p) = *reinterpret_cast<const float4*>(h + p);
+    __syncthreads();
+    const float dmp = *damp;
+    for (int j = threadIdx.x; j <= i; j += 512) a[j] = rowbuf[perm[C - 1 - j]] + (j == i ? dmp : 0.f);
+    __syncthreads();
+  }
+}
+
 // acc(32x32, MFMA C layout) += sign * A * B  over K = 32, operands addressed as A(i,k) = Ap[i*lda + k],
 // B(k,j) = Bp[j*ldb + k]  (i.e. B given as its transpose, row-major), all in LDS.
 __device__ __forceinline__ void lds_mfma32(f32x16& acc, const float* Ap, int lda, const float* Bp, int ldb,
@@ -441,7 +464,15 @@ static int factor_chain(float* H, int ldh, int C, float percdamp, const int32_t*
   float* damp = cv.take<float>(64);
 
   diag_mean_kernel<<<1, 256, 0, s>>>(H, ldh, C, percdamp, damp, info);
-  build_abar_kernel<<<dim3(cdiv(Cp, 256), Cp), 256, 0, s>>>(H, ldh, C, Cp, perm, damp, A);
+  const bool lds_gather = perm && C % 4 == 0 && ldh % 4 == 0 && C <= 36864 && reinterpret_cast<uintptr_t>(H) % 16 == 0;
+  if (lds_gather) {
+    if (int rc = gptq_symmetrize(H, ldh, C, stream)) return rc;   // (H is consumed: its lower triangle is free)
+    GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&build_abar_perm_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * C)));
+    build_abar_perm_kernel<<<std::min(Cp, 2048), 512, sizeof(float) * C, s>>>(H, ldh, C, Cp, perm, damp, A);
+  } else {
+    build_abar_kernel<<<dim3(cdiv(Cp, 256), Cp), 256, 0, s>>>(H, ldh, C, Cp, perm, damp, A);
+  }
   // Look-ahead: the far update of an outer panel is split into "the next outer panel's block columns" (caller's stream:
   // the factorization needs them next) and "everything beyond" (helper stream, underneath the next outer panel's steps,
   // which are serial and latency-bound).

@@ -37,23 +37,31 @@ __global__ void zero_dead_kernel(float* __restrict__ W, int ldw, int R, int C,
 }
 
 // perm = argsort(diag, descending), stable on ties (gptq.py:166; torch leaves tie order unspecified).
+// Rank by counting: 64 elements per workgroup, the four lanes of a quad split every 1024-value tile of `diag` between
+// them (16-byte LDS reads, interleaved so that a wave's four addresses fall into different banks).
 __global__ __launch_bounds__(256) void argsort_desc_kernel(const float* __restrict__ diag, int C,
                                                            int32_t* __restrict__ perm) {
-  __shared__ float tile[1024];
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  __shared__ __attribute__((aligned(16))) float tile[1024];
+  const int i = blockIdx.x * 64 + (threadIdx.x >> 2), part = threadIdx.x & 3;
   const float di = (i < C) ? diag[i] : 0.f;
   int rank = 0;
   for (int j0 = 0; j0 < C; j0 += 1024) {
     __syncthreads();
-    for (int t = threadIdx.x; t < 1024; t += 256) tile[t] = (j0 + t < C) ? diag[j0 + t] : 0.f;
+    for (int t = threadIdx.x; t < 1024; t += 256) tile[t] = (j0 + t < C) ? diag[j0 + t] : -INFINITY;   // padding never counts
     __syncthreads();
-    const int n = min(1024, C - j0);
-    for (int t = 0; t < n; ++t) {
-      const float dj = tile[t];
-      rank += (dj > di) || (dj == di && j0 + t < i);
+#pragma unroll 4
+    for (int q = part; q < 256; q += 4) {
+      const float4 d = *reinterpret_cast<const float4*>(tile + 4 * q);
+      const int j = j0 + 4 * q;
+      rank += (d.x > di) || (d.x == di && j < i);
+      rank += (d.y > di) || (d.y == di && j + 1 < i);
+      rank += (d.z > di) || (d.z == di && j + 2 < i);
+      rank += (d.w > di) || (d.w == di && j + 3 < i);
     }
   }
-  if (i < C) perm[rank] = i;
+  rank += __shfl_xor(rank, 1);
+  rank += __shfl_xor(rank, 2);
+  if (i < C && part == 0) perm[rank] = i;
 }
 
 // dst[r][p] = src[r][perm[p]]  (gather = gptq.py:167)  or  dst[r][perm[p]] = src[r][p] (scatter = :301)
@@ -616,7 +624,7 @@ extern "C" int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R
 
   // dead columns (gptq.py:143-145)
   dead_fix_kernel<<<cdiv(C, TB), TB, 0, s>>>(H, ldh, C, ws.dead, ws.diag);
-  if (actorder) argsort_desc_kernel<<<cdiv(C, 256), 256, 0, s>>>(ws.diag, C, ws.perm);   // gptq.py:166
+  if (actorder) argsort_desc_kernel<<<cdiv(C, 64), 256, 0, s>>>(ws.diag, C, ws.perm);   // gptq.py:166
   // Everything that prepares W (dead columns zeroed, static-group grids, act-order gather, full-row grid) depends on
   // diag(H) only, not on the factorization: it runs on the helper stream beside the chain below, which is serial and
   // latency-bound and leaves the chip idle.  (No helper stream: same kernels, caller's stream.)
