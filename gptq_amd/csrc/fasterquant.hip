@@ -33,7 +33,7 @@ __global__ void zero_dead_kernel(float* __restrict__ W, int ldw, int R, int C,
                                  const int32_t* __restrict__ dead) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C || !dead[c]) return;
-  for (long r = blockIdx.y; r < R; r += gridDim.y) W[r * ldw + c] = 0.f;      // (grid.y is capped at 65535 rows)
+  for (long r = blockIdx.y; r < R; r += gridDim.y) W[r * ldw + c] = 0.f;      // (grid.y strides over the rows)
 }
 
 // perm = argsort(diag, descending), stable on ties (gptq.py:166; torch leaves tie order unspecified).
@@ -635,7 +635,7 @@ extern "C" int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R
     GPTQ_CHECK_HIP(hipStreamWaitEvent(sc->stream, sc->main_done, 0));
     ps = sc->stream;
   }
-  zero_dead_kernel<<<dim3(cdiv(C, TB), std::min(R, 65535)), TB, 0, ps>>>(W, ldw, R, C, ws.dead);
+  zero_dead_kernel<<<dim3(cdiv(C, TB), std::min(R, 256)), TB, 0, ps>>>(W, ldw, R, C, ws.dead);   // (usually nothing is dead: few workgroups)
   // static groups: grids of the ORIGINAL, uncompensated columns (gptq.py:157-163)
   if (use_static)
     find_params_kernel<<<dim3(cdiv(R, 4), G), 256, 0, ps>>>(W, ldw, R, 0, C, groupsize, maxq, sym,
