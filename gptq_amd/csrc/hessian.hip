@@ -439,8 +439,60 @@ struct BigPlan {
   float* ws;            // workers x 2 partial tiles of 256 x 256 fp32
   int item0;            // first work item of THIS launch (launches by rounds, see hessian_launch_big)
   int item1;            // one past its last work item
+  int head;             // > 0: heads + tails (below) instead of equal runs of the (tile, stage) sequence
 };
 constexpr int BTILE_FLOATS = BT * BT;
+
+// Heads + tails.  Equal contiguous runs leave every worker of the split round at its own K offset, so nothing an XCD's
+// 32 workgroups fetch is shared: at C = 11008 that round moved 5.6 GB in 0.82 ms (6.9 TB/s, HBM-bound) while a whole
+// round of 256 tiles moves 2.1-2.4 GB in 0.88 ms.  With `head` = chunk the first `left_tiles` workers take stages
+// [0, head) of ONE tile each -- they start together and walk K in step like a whole round -- and only the remaining
+// workers take equal runs of the concatenated tails [head, nk_all); a run then touches up to BIG_MAXSEG tiles.
+// Partial slots: worker w < left_tiles owns slot w, tail worker v owns slots left_tiles + BIG_MAXSEG v + seg.
+constexpr int BIG_MAXSEG = 4;
+// segment `seg` of split worker `wi`: left tile l, stages [s0, s1), partial slot; false = no such segment
+__device__ __forceinline__ bool big_segment(const BigPlan& plan, int wi, int seg, int nk_all, int& l, int& s0, int& s1,
+                                            int& slot) {
+  if (plan.head == 0) {
+    if (seg >= 2) return false;
+    const int run_begin = wi * plan.chunk, run_end = min(run_begin + plan.chunk, plan.left_tiles * nk_all);
+    l = run_begin / nk_all + seg;
+    s0 = seg == 0 ? run_begin - l * nk_all : 0;
+    s1 = min(run_end - l * nk_all, nk_all);
+    slot = wi * 2 + seg;
+    return s1 > s0;
+  }
+  if (wi < plan.left_tiles) {
+    l = wi; s0 = 0; s1 = plan.head; slot = wi;
+    return seg == 0;
+  }
+  const int tl = nk_all - plan.head, v = wi - plan.left_tiles;
+  const int tb = v * plan.chunk, te = min(tb + plan.chunk, plan.left_tiles * tl);
+  l = tb / tl + seg;
+  if (l >= plan.left_tiles) return false;
+  s0 = seg == 0 ? tb - l * tl : 0;
+  s1 = min(te - l * tl, tl);
+  slot = plan.left_tiles + v * BIG_MAXSEG + seg;
+  if (s1 <= s0) return false;
+  s0 += plan.head;
+  s1 += plan.head;
+  return true;
+}
+// the partial slots of left tile l, in the fixed order they are summed: calls f(slot)
+template <typename F>
+__device__ __forceinline__ void big_for_each_partial(const BigPlan& plan, int l, int nk_all, F f) {
+  if (plan.head == 0) {
+    const int first = l * nk_all, last = first + nk_all - 1;
+    const int w0 = first / plan.chunk, w1 = min(last / plan.chunk, plan.workers - 1);
+    for (int w = w0; w <= w1; ++w) f(w * 2 + ((w * plan.chunk < first) ? 1 : 0));   // 1: the run began in the previous tile
+    return;
+  }
+  f(l);
+  const int tl = nk_all - plan.head, ntail = plan.workers - plan.left_tiles;
+  const int tb = l * tl, te = tb + tl - 1;
+  const int v0 = tb / plan.chunk, v1 = min(te / plan.chunk, ntail - 1);
+  for (int v = v0; v <= v1; ++v) f(plan.left_tiles + v * BIG_MAXSEG + (l - (v * plan.chunk) / tl));
+}
 
 // register (t, u, e) of wave `wave`, lane `lane`  <->  element of the 256 x 256 tile (C/D map of the 32x32 MFMA:
 // col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)); partial tiles are stored in register
@@ -772,22 +824,15 @@ __global__ __launch_bounds__(512) void hessian16_big16_kernel(ProbGroup pg, BigP
   // work items: [0, dp_tiles) whole tiles, then `workers` K-split runs; a launch sized for a CU budget has fewer
   // workgroups than items and every workgroup strides over them
   for (int bid = plan.item0 + blockIdx.x; bid < plan.item1; bid += gridDim.x) {
-  int run_begin = 0, run_end = 0;
   const bool whole = bid < plan.dp_tiles;
-  if (!whole) {
-    run_begin = (bid - plan.dp_tiles) * plan.chunk;
-    run_end = min(run_begin + plan.chunk, plan.left_tiles * nk_all);
-  }
-  for (int seg = 0; seg < 2; ++seg) {
-    int tile, s0, s1;
+  for (int seg = 0; seg < BIG_MAXSEG; ++seg) {
+    int tile, s0, s1, slot = 0;
     if (whole) {
       if (seg == 1) break;
       tile = bid; s0 = 0; s1 = nk_all;
     } else {
-      const int l = run_begin / nk_all + seg;
-      s0 = seg == 0 ? run_begin - l * nk_all : 0;
-      s1 = min(run_end - l * nk_all, nk_all);
-      if (s1 <= s0) break;
+      int l;
+      if (!big_segment(plan, bid - plan.dp_tiles, seg, nk_all, l, s0, s1, slot)) break;
       tile = plan.dp_tiles + l;
     }
     const int prob = prob_of_tile(pg, tile);
@@ -912,7 +957,7 @@ __global__ __launch_bounds__(512) void hessian16_big16_kernel(ProbGroup pg, BigP
         big16_epilogue_rows(H, ldh, ti, tj, wm, wn, lane, t2, v, alpha, beta);
       }
     } else {
-      float* __restrict__ part = plan.ws + ((long)(bid - plan.dp_tiles) * 2 + seg) * BTILE_FLOATS;
+      float* __restrict__ part = plan.ws + (long)slot * BTILE_FLOATS;
 #pragma unroll
       for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -933,8 +978,6 @@ __global__ __launch_bounds__(512) void hessian16_big16_fixup(ProbGroup pg, BigPl
   hessian_tile_of(tile - pg.tile_start[prob], pg.C[prob] / BT, ti, tj);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 2, wn = wave & 3;
-  const int first = l * nk_all, last = first + nk_all - 1;
-  const int w0 = first / plan.chunk, w1 = min(last / plan.chunk, plan.workers - 1);
   float* __restrict__ H = pg.H[prob];
   const float alpha = pg.alpha[prob], beta = pg.beta[prob];
   const int t2 = blockIdx.y;
@@ -945,16 +988,15 @@ __global__ __launch_bounds__(512) void hessian16_big16_fixup(ProbGroup pg, BigPl
     for (int u = 0; u < 4; ++u)
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[tt][u][e] = 0.f;
-  for (int w = w0; w <= w1; ++w) {
-    const int seg = (w * plan.chunk < first) ? 1 : 0;
-    const float* __restrict__ part = plan.ws + ((long)w * 2 + seg) * BTILE_FLOATS;
+  big_for_each_partial(plan, l, nk_all, [&](int slot) {
+    const float* __restrict__ part = plan.ws + (long)slot * BTILE_FLOATS;
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[tt][u][e] += part[big16_part_index(wave, 2 * t2 + tt, u, e, lane)];
-  }
+  });
   big16_epilogue_rows(H, ldh, ti, tj, wm, wn, lane, t2, v, alpha, beta);
 }
 
@@ -1029,7 +1071,7 @@ static int hessian_launch_big(const HostProb* probs, int n_prob, int n_x, int x_
       const int nk_all = tokens / BBK * nx;
       static const int shape_env = [] { const char* e = getenv("GPTQ_HESS_SHAPE"); return e ? atoi(e) : 16; }();
       const bool shape16 = shape_env == 16 && nk_all % 2 == 0;
-      BigPlan plan{total, 0, 0, 1, nullptr, 0, 0};   // dp_tiles, left_tiles, workers, chunk, ws, item0, item1
+      BigPlan plan{total, 0, 0, 1, nullptr, 0, 0, 0};   // dp_tiles, left_tiles, workers, chunk, ws, item0, item1, head
       const int full = total / n_cu * n_cu, left = total - full;
       // cut the last round along K when it would run under 90 % full and a run still has >= 8 stages
       if (big_env != 3 && left > 0 && left * 10 < n_cu * 9 && (long)left * nk_all >= 8L * n_cu) {
@@ -1038,9 +1080,23 @@ static int hessian_launch_big(const HostProb* probs, int n_prob, int n_x, int x_
         plan.chunk = cdiv((long)left * nk_all, n_cu);
         if (shape16) plan.chunk += plan.chunk & 1;                  // the 16x16x32 kernel walks stages in pairs
         plan.workers = cdiv((long)left * nk_all, plan.chunk);
-        plan.ws = static_cast<float*>(scratch_buffer(s, sizeof(float) * 2 * BTILE_FLOATS * (size_t)plan.workers));
+        size_t slots = 2 * (size_t)plan.workers;
+        // heads + tails (16x16x32 kernel; see BigPlan): while a tail run touches at most BIG_MAXSEG tiles
+        static const int heads_env = [] { const char* e = getenv("GPTQ_HESS_HEADS"); return e ? atoi(e) : 1; }();
+        const int tail_len = nk_all - plan.chunk;
+        // (measured: the split round of C = 11008, 178 tiles, 0.83 -> 0.60 ms and 5.6 -> 3.0 GB; but 4-7 % SLOWER at
+        //  136 tiles (C = 4096) and 16 tiles (C = 8192), where equal runs happen to line up and more segments cost more
+        //  than the traffic they save: taken from 60 % of a round on)
+        if (heads_env && shape16 && tail_len > 0 && cdiv(plan.chunk, tail_len) + 1 <= BIG_MAXSEG &&
+            (heads_env == 2 || left * 10 >= n_cu * 6)) {
+          plan.head = plan.chunk;
+          const int ntail = cdiv((long)left * tail_len, plan.chunk);
+          plan.workers = left + ntail;
+          slots = (size_t)left + (size_t)BIG_MAXSEG * ntail;
+        }
+        plan.ws = static_cast<float*>(scratch_buffer(s, sizeof(float) * BTILE_FLOATS * slots));
         GPTQ_CHECK_ARG(plan.ws != nullptr, "gptq_hessian_accum: cannot allocate the %zu-byte split-K workspace",
-                       sizeof(float) * 2 * BTILE_FLOATS * (size_t)plan.workers);
+                       sizeof(float) * BTILE_FLOATS * slots);
       }
       // One launch per ROUND of n_cu work items instead of one launch for all of them: the workgroups of a launch start
       // together, so the tiles an XCD runs side by side walk K in step and share their operand panels in its L2.  In a
