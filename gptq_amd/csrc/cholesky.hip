@@ -153,6 +153,7 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
   // ONE 128 x 129 image (66 KB) serves the block, its factor and its inverse: a sub-block's inverse replaces it as
   // soon as it is final.  The footprint matters: the kernel is a single workgroup on the critical path and must find
   // a compute unit with that much free LDS beside the big low-priority updates of the helper stream.
+  critical_path_priority();
   constexpr int LD = NB + 1;            // 129: row-strided accesses (lane = row) are conflict-free
   extern __shared__ __attribute__((aligned(16))) float dsm[];
   float* S = dsm;                       // [128][129]  A_kk (full, mirrored) -> L off-diagonal blocks -> L_kk^-1
@@ -294,6 +295,7 @@ constexpr size_t POTRF_LDS = sizeof(float) * (NB * (NB + 1) + 32 * 33);
 // (its rows are read by nobody else), i.e. half the serial MFMA time of one workgroup per 128 x 128 block.
 __global__ __launch_bounds__(GEMM_THREADS) void panel_kernel(float* __restrict__ A,
                                                              const float* __restrict__ Linv, int Cp, int kb) {
+  critical_path_priority();
   __shared__ __attribute__((aligned(16))) float smem[GEMM64_LDS_FLOATS];
   const int tm = kb + 1 + (blockIdx.x >> 1), sm = blockIdx.x & 1;
   float* P = A + ((long)tm * NB + 64 * sm) * Cp + (long)kb * NB;
@@ -319,6 +321,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void syrk_kernel(float* __restrict__ 
                                                             int tn0, int tn1) {
   // 64 x 64 output tiles (gemm2_f32.h): blockIdx.y selects the quarter (sm, sn) of a 128 x 128 block.  Measured on
   // the launches of one step (31 ... 255 blocks): up to 2x faster than one workgroup per block, bit-identical.
+  critical_path_priority();
   __shared__ __attribute__((aligned(16))) float smem[GEMM64_LDS_FLOATS];
   int rest = blockIdx.x, tn = tn0;             // column block tn, row block tm >= tn
   while (rest >= nblk - tn) { rest -= nblk - tn; ++tn; }

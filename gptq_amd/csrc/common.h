@@ -52,6 +52,12 @@ SideCtx* side_ctx(hipStream_t main);   // nullptr if it cannot be created (calle
 void* scratch_buffer(hipStream_t main, size_t bytes);
 int lookahead_mask();               // bit 0: factorization chain, bit 1: column loop (env GPTQ_LOOKAHEAD)
 
+// Kernels of the caller's stream in the solve (the serial chain) raise their waves' issue priority over the helper
+// stream's far-update GEMMs that share their SIMDs (s_setprio: 0 = default ... 3).
+#if defined(__HIPCC__)
+__device__ __forceinline__ void critical_path_priority() { __builtin_amdgcn_s_setprio(3); }
+#endif
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -356,6 +356,7 @@ __device__ __forceinline__ void quant_phase(const QuantBlockArgs& a, float (&w)[
 
 template <int NPH, bool GROUPED, int ABL = 0>
 __global__ __launch_bounds__(256) void quant_block_kernel(QuantBlockArgs a) {
+  critical_path_priority();
   constexpr int B = 32 * NPH;
   constexpr int NREG = 8 * NPH;
   constexpr int LDCL = NREG + 4;               // padded class row (16-B aligned, conflict-free b128)
@@ -408,6 +409,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void trailing_kernel(float* __restric
                                                                 bool bvec) {
   // 64 x 64 output tiles (gemm2_f32.h): 2x faster than 128 x 128 ones on the small launches inside a super-block,
   // never slower on the large ones, bit-identical
+  critical_path_priority();
   __shared__ __attribute__((aligned(16))) float smem[GEMM64_LDS_FLOATS];
   const int tn = blockIdx.x, tm = blockIdx.y;
   const long r0 = (long)tm * SBM, c0 = (long)c_begin + (long)tn * SBN;
