@@ -7,12 +7,15 @@ Bars:
                 / 1e-2 (fp16 x) against the fp64 formula.
 """
 import math
+import os
 
 import numpy as np
 import pytest
 import torch
 
 from conftest import golden_names, load_golden, record_parity
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -230,6 +233,30 @@ def test_rfactor_upper_fp64(G, C, actorder):
     from gptq_amd import _lib
     with pytest.raises(_lib.GptqHipError):
         _hinv_gpu(H[:200, :200].contiguous(), 0.01, entry="gptq_rfactor_upper")
+
+
+@pytest.mark.timeout(300)
+def test_factor_form_matches_inverse_form_of_the_solve():
+    """gptq_fasterquant's factor form (no triangular inverse) against its inverse form (GPTQ_RFORM=0) on the same inputs,
+    in child processes (the form is fixed when the library loads): the two differ by fp32 summation order only, so at
+    most a couple of ROWS may differ (a flipped code drags the rest of its row along) -- the rate at which either form
+    differs from the reference (tools/rform_compare.py; observed: 0 rows on these shapes)."""
+    import re
+    import subprocess
+    import sys
+    tool = os.path.join(ROOT, "tools", "rform_compare.py")
+    for extra in (["33x256", "1000x640", "512x1408"], ["70x384", "1024x1408", "--actorder"],
+                  ["70x384", "33x256", "--groupsize", "64", "--dynamic"]):
+        out = subprocess.run([sys.executable, tool] + extra, check=True, capture_output=True, text=True, timeout=280).stdout
+        lines = [l for l in out.splitlines() if "codes differ" in l]
+        assert len(lines) == sum("x" in a for a in extra), out
+        for l in lines:
+            assert "rfactor vs hinv" in l, l
+            rows = int(re.search(r"\((\d+) rows\)", l).group(1))
+            ea, eb = (float(v) for v in re.search(r"error ([0-9.e+-]+) vs ([0-9.e+-]+)", l).groups())
+            record_parity("rform_" + l.split(":")[0] + "_" + "_".join(a.strip("-") for a in extra if not "x" in a),
+                          rows_differ=rows, error_factor=ea, error_inverse=eb)
+            assert rows <= 2 and abs(ea - eb) <= 1e-3 * abs(eb), l
 
 
 def test_hinv_not_positive_definite_raises(G, hip_device):
