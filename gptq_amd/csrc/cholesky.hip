@@ -6,6 +6,9 @@
 //   Abar = L L^T                   (blocked right-looking Cholesky, fp32 MFMA trailing updates)
 //   => H + damp I = R R^T with R = J L J upper triangular, hence (H + damp I)^-1 = R^-T R^-1
 //   U = R^-1 = J L^-1 J            (L^-1 by recursive doubling: log2(C/128) levels of batched GEMMs)
+// gptq_rfactor_upper stops after the Cholesky (C^3 / 3): the column loop's cross-block compensation can run on the
+// FACTOR's rows (e = (w0 - q) R, see fasterquant.hip), so it leaves Rt = R blockdiag(U_kk) above the diagonal 128-blocks
+// and U_kk = R_kk^-1 inside them -- no triangular inverse.
 // All arithmetic is IEEE fp32 (no TF32/bf16), like gptq.py:18-19.
 #include <stdlib.h>
 
