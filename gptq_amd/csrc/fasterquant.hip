@@ -354,8 +354,10 @@ __device__ __forceinline__ void quant_phase(const QuantBlockArgs& a, float (&w)[
   if (PH + 1 < NPH) stage_store<NPH>(Us_next, tid, nxt);
 }
 
-template <int NPH, bool GROUPED, int ABL = 0>
-__global__ __launch_bounds__(256) void quant_block_kernel(QuantBlockArgs a) {
+// OCC = 2: at most 256 registers, so that two workgroups fit a compute unit -- for more than 256 workgroups (R > 16384),
+// which otherwise run as two rounds (the kernel's natural allocation is ~290 registers: one wave per SIMD).
+template <int NPH, bool GROUPED, int ABL = 0, int OCC = 1>
+__global__ __launch_bounds__(256, OCC) void quant_block_kernel(QuantBlockArgs a) {
   critical_path_priority();
   constexpr int B = 32 * NPH;
   constexpr int NREG = 8 * NPH;
@@ -517,6 +519,13 @@ static int launch_quant_block(const QuantBlockArgs& a, int blocksize, bool group
     if (grouped) quant_block_kernel<NPH, true><<<grid, 256, 0, s>>>(a);               \
     else quant_block_kernel<NPH, false><<<grid, 256, 0, s>>>(a);                      \
     break;
+  static const int occ_env = [] { const char* e = getenv("GPTQ_QB_OCC"); return e ? atoi(e) : 0; }();
+  if (blocksize > 64 && blocksize <= 128 && (occ_env == 2 || (occ_env == 0 && grid > 256))) {
+    if (grouped) quant_block_kernel<4, true, 0, 2><<<grid, 256, 0, s>>>(a);
+    else quant_block_kernel<4, false, 0, 2><<<grid, 256, 0, s>>>(a);
+    GPTQ_CHECK_LAUNCH("quant_block_kernel");
+    return GPTQ_OK;
+  }
   int nph = 1;
   while (nph * 32 < blocksize) nph *= 2;
   switch (nph) {
