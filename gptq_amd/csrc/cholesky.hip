@@ -130,22 +130,26 @@ __device__ __forceinline__ void acc_store(const f32x16& acc, float* T, int ld, i
 // The sub-panel below D is then a plain product with D^-1 (MFMA) instead of a per-row substitution.
 // ---------------------------------------------------------------------------------------------
 template <int J>
-__device__ __forceinline__ void factor32_step(f32x16& S, f32x16& M, float* Xd, int ldx, float* Ld, int32_t* info,
-                                              int col0, int lane) {
+__device__ __forceinline__ void factor32_step(f32x16& S, f32x16& M, float* Xd, int ldx, float* Ld, int& bad, int c,
+                                              int lane) {
   constexpr int e = (J & 3) + 4 * (J >> 3);       // register holding row J
   constexpr int h = (J >> 2) & 1;                 // half of the wave holding row J
-  const int c = lane & 31;
   const float srow = S[e];                        // (a copy: __builtin_bit_cast of a vector ELEMENT reads element 0)
   const float ajj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, srow), J + 32 * h));
+  // a non-positive pivot is only REMEMBERED here (first one wins; reported once, after the 32 steps): no branch and
+  // no atomic on the chain
+  bad = (bad == 0 && !(ajj > 0.f)) ? J + 1 : bad;
   // 1/sqrt by v_rsq_f32 + one Newton step, l_jj = a_jj * that (tolerance-level, like the rest of the chain)
   float inv = __builtin_amdgcn_rsqf(ajj);
-  inv = inv * (1.5f - 0.5f * ajj * inv * inv);
-  if (!(ajj > 0.f) && lane == 0 && info) atomicCAS(info, 0, col0 + J + 1);
+  inv = inv * __builtin_fmaf(-0.5f * ajj * inv, inv, 1.5f);
+  // `c` is laundered by the caller once per step, so that the 64 lane masks (c >= J, c > J) are compared here, in the
+  // shadow of the MFMAs, instead of being hoisted out of the 32 steps into scalar registers that spill
   const bool mine = (lane >> 5) == h;
   const float l = (mine && c >= J) ? srow * inv : 0.f;          // column J of L_D, l_J = sqrt(a_JJ)
   const float x = mine ? M[e] * inv : 0.f;                      // row J of L_D^-1 (exact zeros right of the diagonal)
-  if (mine) Xd[J * ldx + c] = x;
-  if (mine) Ld[c * 33 + J] = l;                                  // column J of L_D (zeros above the diagonal)
+  // both halves store (the idle half into a scratch row / column behind the images): no exec-mask branch per step
+  *(mine ? Xd + J * ldx + c : Ld + 32 * 33 + c) = x;            // (32 scratch floats behind Ld)
+  Ld[c * 33 + (mine ? J : 32)] = l;                             // column J of L_D; column 32 of the 33-wide buffer is scratch
   const float ls = (c > J) ? l : 0.f;
   S = __builtin_amdgcn_mfma_f32_32x32x2f32(-l, l, S, 0, 0, 0);
   M = __builtin_amdgcn_mfma_f32_32x32x2f32(-ls, x, M, 0, 0, 0);
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
   extern __shared__ __attribute__((aligned(16))) float dsm[];
   float* S = dsm;                       // [128][129]  A_kk (full, mirrored) -> L off-diagonal blocks -> L_kk^-1
   float* Tt = S + 64;                   // [64][LD]    level-2 intermediate, in the dead quadrant S[0:64, 64:128]
-  float* Ld = S + NB * LD;              // [32][33]    factor of the current diagonal 32 x 32 sub-block
+  float* Ld = S + NB * LD;              // [32][33]    factor of the current diagonal 32 x 32 sub-block (+ 32 scratch floats)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* Ak = A + (long)kb * NB * Cp + (long)kb * NB;
@@ -188,12 +192,14 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
       for (int e = 0; e < 16; ++e) M[e] = ((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) == (lane & 31)) ? 1.f : 0.f;
       float* Xd = S + o * LD + o;                               // X_D takes D's place (D lives in registers now)
       const int c0 = kb * NB + o;
-#define FSTEP(J) factor32_step<J>(D, M, Xd, LD, Ld, info, c0, lane)
+      int bad = 0, cl = lane & 31;
+#define FSTEP(J) asm volatile("" : "+v"(cl)); factor32_step<J>(D, M, Xd, LD, Ld, bad, cl, lane)
       FSTEP(0); FSTEP(1); FSTEP(2); FSTEP(3); FSTEP(4); FSTEP(5); FSTEP(6); FSTEP(7);
       FSTEP(8); FSTEP(9); FSTEP(10); FSTEP(11); FSTEP(12); FSTEP(13); FSTEP(14); FSTEP(15);
       FSTEP(16); FSTEP(17); FSTEP(18); FSTEP(19); FSTEP(20); FSTEP(21); FSTEP(22); FSTEP(23);
       FSTEP(24); FSTEP(25); FSTEP(26); FSTEP(27); FSTEP(28); FSTEP(29); FSTEP(30); FSTEP(31);
 #undef FSTEP
+      if (bad && lane == 0 && info) atomicCAS(info, 0, c0 + bad);
     }
     __syncthreads();
     const int nb_rem = 3 - s;                                   // 32-row blocks under the diagonal sub-block
@@ -290,7 +296,7 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
     Xk[(long)i * Cp + k] = (k <= i) ? S[i * LD + k] : 0.f;
   }
 }
-constexpr size_t POTRF_LDS = sizeof(float) * (NB * (NB + 1) + 32 * 33);
+constexpr size_t POTRF_LDS = sizeof(float) * (NB * (NB + 1) + 32 * 33 + 32);
 
 
 // Panel:  P <- P * inv(L_kk)^T  for the block column kb below the diagonal (rows (kb+1)*128 ...), IN PLACE.
