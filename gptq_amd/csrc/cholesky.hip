@@ -152,9 +152,19 @@ __device__ __forceinline__ void factor32_step(f32x16& S, f32x16& M, float* Xd, i
   Ld[c * 33 + (mine ? J : 32)] = l;                             // column J of L_D; column 32 of the 33-wide buffer is scratch
   const float ls = (c > J) ? l : 0.f;
   S = __builtin_amdgcn_mfma_f32_32x32x2f32(-l, l, S, 0, 0, 0);
+#ifdef GPTQ_DIAG
+  if (bad < 0) return;                                          // timing-only ablation: no inverse (see potrf_phases.py)
+#endif
   M = __builtin_amdgcn_mfma_f32_32x32x2f32(-ls, x, M, 0, 0, 0);
 }
 
+#ifdef GPTQ_DIAG   // diagnostic library only: s_memtime at the phase boundaries of the LAST launch (100 MHz... see tools)
+__device__ unsigned long long potrf_stamps[32];
+__device__ int potrf_ablate;
+#define POTRF_STAMP(i) do { if (threadIdx.x == 0) potrf_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define POTRF_STAMP(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__ A, float* __restrict__ Linv,
                                                              int Cp, int kb, int32_t* __restrict__ info) {
   // ONE 128 x 129 image (66 KB) serves the block, its factor and its inverse: a sub-block's inverse replaces it as
@@ -170,16 +180,29 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* Ak = A + (long)kb * NB * Cp + (long)kb * NB;
 
-  for (int idx = tid; idx < NB * NB; idx += 512) {              // coalesced: lower triangle only
-    const int i = idx >> 7, k = idx & 127;
-    if (k <= i) S[i * LD + k] = Ak[(long)i * Cp + k];
+  POTRF_STAMP(0);
+  {
+    // the lower triangle, coalesced, ALL 32 loads of a thread in flight before the first one is used (the plain loop
+    // took 21 k of the kernel's 106 k cycles: one L2 round trip per iteration), mirrored while it is stored (diagonal
+    // tiles are kept full; the transposed store has stride 129: conflict-free)
+    float v[NB * NB / 512];
+#pragma unroll
+    for (int j = 0; j < NB * NB / 512; ++j) {
+      const int idx = tid + 512 * j, i = idx >> 7, k = idx & 127;
+      v[j] = (k <= i) ? Ak[(long)i * Cp + k] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < NB * NB / 512; ++j) {
+      const int idx = tid + 512 * j, i = idx >> 7, k = idx & 127;
+      if (k <= i) {
+        S[i * LD + k] = v[j];
+        S[k * LD + i] = v[j];
+      }
+    }
   }
   __syncthreads();
-  for (int idx = tid; idx < NB * NB; idx += 512) {              // mirror inside LDS (diagonal tiles are kept full)
-    const int i = idx >> 7, k = idx & 127;
-    if (k > i) S[i * LD + k] = S[k * LD + i];
-  }
-  __syncthreads();
+  POTRF_STAMP(1);
+  POTRF_STAMP(2);
 
   // ------------------------------- factorization -------------------------------
 #pragma unroll 1
@@ -193,6 +216,10 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
       float* Xd = S + o * LD + o;                               // X_D takes D's place (D lives in registers now)
       const int c0 = kb * NB + o;
       int bad = 0, cl = lane & 31;
+#ifdef GPTQ_DIAG
+      if (kb < 0) bad = -1;                                     // (never true: keeps `bad < 0` opaque) ...
+      if (potrf_ablate) bad = -1;
+#endif
 #define FSTEP(J) asm volatile("" : "+v"(cl)); factor32_step<J>(D, M, Xd, LD, Ld, bad, cl, lane)
       FSTEP(0); FSTEP(1); FSTEP(2); FSTEP(3); FSTEP(4); FSTEP(5); FSTEP(6); FSTEP(7);
       FSTEP(8); FSTEP(9); FSTEP(10); FSTEP(11); FSTEP(12); FSTEP(13); FSTEP(14); FSTEP(15);
@@ -202,11 +229,12 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
       if (bad && lane == 0 && info) atomicCAS(info, 0, c0 + bad);
     }
     __syncthreads();
+    POTRF_STAMP(3 + 3 * s);
     const int nb_rem = 3 - s;                                   // 32-row blocks under the diagonal sub-block
     // L_kk itself goes back to A (the column loop's far updates multiply with the FACTOR, see gptq_rfactor_upper):
     // the diagonal sub-block's factor now, by a wave that has nothing to do in (A2); the blocks under it in (A3)
-    if (wave == 7) {
-      for (int idx = lane; idx < 32 * 32; idx += 64) {
+    if (wave >= 4) {                                            // (four waves: one took 2.7 k cycles, the whole phase)
+      for (int idx = (wave - 4) * 64 + lane; idx < 32 * 32; idx += 256) {
         const int i = idx >> 5, k = idx & 31;
         if (k <= i) Ak[(long)(o + i) * Cp + o + k] = Ld[i * 33 + k];
       }
@@ -220,6 +248,7 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
       acc_store(acc, S + ri * LD + o, LD, lane);
     }
     __syncthreads();
+    POTRF_STAMP(4 + 3 * s);
     {                                                           // (A3) S[I,K] -= P_I P_K^T, s < K <= I
       const int ntile = nb_rem * (nb_rem + 1) / 2;
       if (wave < ntile) {
@@ -240,6 +269,7 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
       }
     }
     __syncthreads();
+    POTRF_STAMP(5 + 3 * s);
   }
 
   // ---------------------------------- inverse ----------------------------------
@@ -290,11 +320,14 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
     acc_store(X, S + (64 + 32 * I) * LD + 32 * J, LD, lane);    // over L[64:128, 0:64] (dead since the barrier)
   }
   __syncthreads();
+  POTRF_STAMP(15);
   float* Xk = Linv + (long)kb * NB * Cp + (long)kb * NB;
+#pragma unroll 8
   for (int idx = tid; idx < NB * NB; idx += 512) {
     const int i = idx >> 7, k = idx & 127;
     Xk[(long)i * Cp + k] = (k <= i) ? S[i * LD + k] : 0.f;
   }
+  POTRF_STAMP(16);
 }
 constexpr size_t POTRF_LDS = sizeof(float) * (NB * (NB + 1) + 32 * 33 + 32);
 
@@ -541,6 +574,17 @@ static int factor_chain(float* H, int ldh, int C, float percdamp, const int32_t*
   GPTQ_CHECK_LAUNCH("gptq_hinv_upper");
   return GPTQ_OK;
 }
+
+#ifdef GPTQ_DIAG
+extern "C" int gptq_diag_potrf_ablate(int v) {
+  GPTQ_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(potrf_ablate), &v, sizeof(int)));
+  return GPTQ_OK;
+}
+extern "C" int gptq_diag_potrf_stamps(unsigned long long* out17) {
+  GPTQ_CHECK_HIP(hipMemcpyFromSymbol(out17, HIP_SYMBOL(potrf_stamps), sizeof(unsigned long long) * 17));
+  return GPTQ_OK;
+}
+#endif
 
 extern "C" int gptq_hinv_upper(float* H, int ldh, int C, float percdamp, const int32_t* perm,
                                int32_t* info, void* workspace, size_t workspace_bytes,
