@@ -215,6 +215,9 @@ struct QuantBlockArgs {
   int errw;  // = blocksize: Err columns [count, errw) are zeroed (the kernel's own width 32 * NPH may be larger)
   const float* w0; int ldw0;   // nullable: the ORIGINAL weights (same layout as W); Err then receives Q1 - W0 instead of
                                // Err1 (factor form of the trailing updates, see gptq_fasterquant_rows)
+  int wide;                    // bit 0: rows of W / Err / w0 allow 16-byte accesses and the block is full: a phase is
+                               // retired through an LDS transpose with 32-byte row pieces per lane instead of 4-byte
+                               // scatters; bit 1: the same for the codes (no column map, 8-byte aligned rows)
 };
 
 // One 32-column phase PH of the block (compile-time, so every "is there a later group" test and every
@@ -248,6 +251,12 @@ __device__ __forceinline__ void stage_store(float* Us, int tid, const float (&v)
   }
 }
 
+#ifdef GPTQ_DIAG   // diagnostic library only: s_memtime at the phase boundaries of workgroup 0 of the LAST launch
+__device__ unsigned long long qb_stamps[32];
+#define QB_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) qb_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define QB_STAMP(i) do { } while (0)
+#endif
 template <int NPH, bool GROUPED, int PH, int ABL = 0>   // ABL: timing-only diagnostic builds (results are wrong)
 __device__ __forceinline__ void quant_phase(const QuantBlockArgs& a, float (&w)[8 * NPH], float* Us, float* Us_next,
                                             const int* grp, const int* cmap, float sc, float zr, bool active,
@@ -261,6 +270,7 @@ __device__ __forceinline__ void quant_phase(const QuantBlockArgs& a, float (&w)[
   // of the NEXT phase are fetched into registers now and stored to the other buffer at the end, so their
   // global / L2 latency hides under the column chain instead of preceding it.
   __syncthreads();
+  QB_STAMP(1 + 3 * PH);
 
   float e[8], cd[8];
 #pragma unroll
@@ -279,10 +289,18 @@ __device__ __forceinline__ void quant_phase(const QuantBlockArgs& a, float (&w)[
     }
   }
   float w0p[8];                                             // factor form: this phase's original weights, for the retire below
+  const bool wide = (a.wide & 1) != 0;                      // (block-uniform)
+  if (wide) {                                               // columns 32 ph + 8 c ... + 7 of the row: the layout after the transpose
+    const float4* p = reinterpret_cast<const float4*>(a.w0 + rbase * a.ldw0 + a.i1 + 32 * ph + 8 * c);
+    float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+    if (a.w0 && active) { lo = p[0]; hi = p[1]; }
+    w0p[0] = lo.x; w0p[1] = lo.y; w0p[2] = lo.z; w0p[3] = lo.w; w0p[4] = hi.x; w0p[5] = hi.y; w0p[6] = hi.z; w0p[7] = hi.w;
+  } else {
 #pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    const int col = 32 * ph + 4 * t + c;
-    w0p[t] = (a.w0 && active && col < a.count) ? a.w0[rbase * a.ldw0 + a.i1 + col] : 0.f;
+    for (int t = 0; t < 8; ++t) {
+      const int col = 32 * ph + 4 * t + c;
+      w0p[t] = (a.w0 && active && col < a.count) ? a.w0[rbase * a.ldw0 + a.i1 + col] : 0.f;
+    }
   }
   const bool tail = !GROUPED && (32 * ph + 32 > a.count);   // block-uniform, false except in a tail block
   // (issued after the grid loads above: vector-memory results return in order)
@@ -338,8 +356,48 @@ __device__ __forceinline__ void quant_phase(const QuantBlockArgs& a, float (&w)[
     }
   }
 
+  QB_STAMP(2 + 3 * PH);
   // retire the window: Q1 -> W, Err1 -> Err, codes
-  if (active) {
+  if (wide) {
+    // The lanes of a quad hold columns 4 t + c: written as they are, every store instruction of a wave touches 16 rows
+    // with 16 bytes each (measured: 6 k of a phase's 25 k cycles went into 24 such stores per thread).  Through LDS (this
+    // phase's U rows are dead) lane c gets columns 8 c ... 8 c + 7 of its row: two 16-byte stores per array.
+    constexpr int TLD = 36;                                      // conflict-free for both access patterns
+    float* T0 = Us;                                              // [64 rows][36]
+    float* T1 = Us + 64 * TLD;                                   // Err1, or (factor form: Err is computed here) the codes
+    const int rl = tid >> 2;
+    const bool codes_wide = a.w0 && a.codes && (a.wide & 2);
+    __syncthreads();                                             // every wave is done with this phase's U rows
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      T0[rl * TLD + 4 * t + c] = w[8 * ph + t];
+      T1[rl * TLD + 4 * t + c] = a.w0 ? cd[t] : e[t];
+    }
+    __syncthreads();
+    const float4 q0 = *reinterpret_cast<const float4*>(T0 + rl * TLD + 8 * c);
+    const float4 q1 = *reinterpret_cast<const float4*>(T0 + rl * TLD + 8 * c + 4);
+    const float4 s0 = *reinterpret_cast<const float4*>(T1 + rl * TLD + 8 * c);
+    const float4 s1 = *reinterpret_cast<const float4*>(T1 + rl * TLD + 8 * c + 4);
+    if (active) {
+      float4 x0 = s0, x1 = s1;
+      if (a.w0) {                                                // factor form: Q1 - W0
+        x0 = make_float4(q0.x - w0p[0], q0.y - w0p[1], q0.z - w0p[2], q0.w - w0p[3]);
+        x1 = make_float4(q1.x - w0p[4], q1.y - w0p[5], q1.z - w0p[6], q1.w - w0p[7]);
+      }
+      float4* wq = reinterpret_cast<float4*>(wrow + 32 * ph + 8 * c);
+      wq[0] = q0; wq[1] = q1;
+      float4* eq = reinterpret_cast<float4*>(a.Err + rbase * a.lde + 32 * ph + 8 * c);
+      eq[0] = x0; eq[1] = x1;
+      if (codes_wide) {
+        const uint32_t lo = (uint32_t)s0.x | ((uint32_t)s0.y << 8) | ((uint32_t)s0.z << 16) | ((uint32_t)s0.w << 24);
+        const uint32_t hi = (uint32_t)s1.x | ((uint32_t)s1.y << 8) | ((uint32_t)s1.z << 16) | ((uint32_t)s1.w << 24);
+        *reinterpret_cast<uint2*>(a.codes + rbase * a.ldc + a.i1 + 32 * ph + 8 * c) = make_uint2(lo, hi);
+      } else if (a.codes) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) a.codes[rbase * a.ldc + cmap[32 * ph + 4 * t + c]] = (uint8_t)cd[t];
+      }
+    }
+  } else if (active) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const int col = 32 * ph + 4 * t + c;
@@ -352,6 +410,7 @@ __device__ __forceinline__ void quant_phase(const QuantBlockArgs& a, float (&w)[
     }
   }
   if (PH + 1 < NPH) stage_store<NPH>(Us_next, tid, nxt);
+  QB_STAMP(3 + 3 * PH);
 }
 
 // OCC = 2: at most 256 registers, so that two workgroups fit a compute unit -- for more than 256 workgroups (R > 16384),
@@ -359,6 +418,7 @@ __device__ __forceinline__ void quant_phase(const QuantBlockArgs& a, float (&w)[
 template <int NPH, bool GROUPED, int ABL = 0, int OCC = 1>
 __global__ __launch_bounds__(256, OCC) void quant_block_kernel(QuantBlockArgs a) {
   critical_path_priority();
+  QB_STAMP(0);
   constexpr int B = 32 * NPH;
   constexpr int NREG = 8 * NPH;
   constexpr int LDCL = NREG + 4;               // padded class row (16-B aligned, conflict-free b128)
@@ -400,6 +460,7 @@ __global__ __launch_bounds__(256, OCC) void quant_block_kernel(QuantBlockArgs a)
   QPHASE(0); QPHASE(1); QPHASE(2); QPHASE(3); QPHASE(4); QPHASE(5); QPHASE(6); QPHASE(7);
 #undef QPHASE
   if (active && c == 0) a.loss[row] += 0.5f * loss;               // gptq.py:274
+  QB_STAMP(1 + 3 * NPH);
 }
 
 // W[:, c_begin:c_end] -= E[:, 0:K] @ U[u0 : u0 + K, c_begin:c_end]   (gptq.py:276), exact-fp32 MFMA.
@@ -499,6 +560,19 @@ extern "C" int gptq_quantize_rows(float* X, int ldx, int R, int C, const float* 
   return GPTQ_OK;
 }
 
+// QuantBlockArgs::wide for a launch (a full block whose rows allow 16-byte accesses; see quant_phase's retire)
+static int quant_block_wide(const QuantBlockArgs& a, int blocksize) {
+  static const int off = [] { const char* e = getenv("GPTQ_QB_WIDE"); return e && atoi(e) == 0; }();
+  auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+  // (128 or 256 columns: the transpose tiles need the U-row buffer of at least four phases; full blocks only)
+  if (off || (blocksize != 128 && blocksize != 256) || a.count != blocksize || a.errw != blocksize) return 0;
+  if (a.ldw % 4 || a.lde % 4 || a.i1 % 4 || !al16(a.W) || !al16(a.Err)) return 0;
+  if (a.w0 && (a.ldw0 % 4 || !al16(a.w0))) return 0;
+  int wide = 1;
+  if (a.codes && !a.col_map && a.ldc % 8 == 0 && a.i1 % 8 == 0 && reinterpret_cast<uintptr_t>(a.codes) % 8 == 0) wide |= 2;
+  return wide;
+}
+
 static int launch_quant_block(const QuantBlockArgs& a, int blocksize, bool grouped, hipStream_t s) {
   const int grid = cdiv(a.R, 64);
 #ifdef GPTQ_DIAG   // timing-only ablation builds (wrong results): diagnostic library only
@@ -551,7 +625,8 @@ extern "C" int gptq_quant_block(float* W, int ldw, int R, int C, int i1, int cou
   GPTQ_CHECK_ARG(ldw >= C && ldu >= C && tab_ld >= 1, "gptq_quant_block: bad leading dimension");
   GPTQ_CHECK_ARG(bits >= 1 && bits <= 8, "gptq_quant_block: bits must be in 1..8");
   QuantBlockArgs a{W, ldw, R, i1, count, U, ldu, scale_tab, zero_tab, tab_ld, col_group,
-                   (float)((1 << bits) - 1), Err, codes, ldc, col_map, loss, blocksize, blocksize, nullptr, 0};
+                   (float)((1 << bits) - 1), Err, codes, ldc, col_map, loss, blocksize, blocksize, nullptr, 0, 0};
+  a.wide = quant_block_wide(a, blocksize);
   return launch_quant_block(a, blocksize, col_group != nullptr, static_cast<hipStream_t>(stream));
 }
 
@@ -595,6 +670,13 @@ SolveWs carve_solve(void* base, int R, int C, int blocksize, int groupsize, int 
   return w;
 }
 }  // namespace
+
+#ifdef GPTQ_DIAG
+extern "C" int gptq_diag_qb_stamps(unsigned long long* out32) {
+  GPTQ_CHECK_HIP(hipMemcpyFromSymbol(out32, HIP_SYMBOL(qb_stamps), sizeof(unsigned long long) * 32));
+  return GPTQ_OK;
+}
+#endif
 
 extern "C" int gptq_fasterquant_factor_form(int C, int blocksize, int groupsize, int static_groups) {
   return use_rform(C, blocksize, groupsize, static_groups) ? 1 : 0;
@@ -718,7 +800,8 @@ extern "C" int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R
         }
       }
       QuantBlockArgs a{Wk, ldk, R, i1, count, H, ldh, ws.stab, ws.ztab, G,
-                       grouped ? ws.cgroup : nullptr, maxq, Err, codes, C, perm, ws.loss, SB, blocksize, rform ? ws.W0 : nullptr, C};
+                       grouped ? ws.cgroup : nullptr, maxq, Err, codes, C, perm, ws.loss, SB, blocksize, rform ? ws.W0 : nullptr, C, 0};
+      a.wide = quant_block_wide(a, blocksize);
       const int rc = launch_quant_block(a, blocksize, grouped, s);
       if (rc != GPTQ_OK) return rc;
       if (i2 < s1)                                                   // the rest of this super-block: rank-blocksize
