@@ -576,6 +576,10 @@ static int factor_chain(float* H, int ldh, int C, float percdamp, const int32_t*
 }
 
 #ifdef GPTQ_DIAG
+extern "C" int gptq_diag_chain64_stamps(unsigned long long* out4) {   // the last 64-tile launch of THIS file
+  GPTQ_CHECK_HIP(hipMemcpyFromSymbol(out4, HIP_SYMBOL(gemm64_stamps), sizeof(unsigned long long) * 4));
+  return GPTQ_OK;
+}
 extern "C" int gptq_diag_potrf_ablate(int v) {
   GPTQ_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(potrf_ablate), &v, sizeof(int)));
   return GPTQ_OK;

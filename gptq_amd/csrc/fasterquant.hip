@@ -672,6 +672,12 @@ SolveWs carve_solve(void* base, int R, int C, int blocksize, int groupsize, int 
 }  // namespace
 
 #ifdef GPTQ_DIAG
+extern "C" int gptq_diag_trailing_stamps(unsigned long long* out4) {   // the last 64-tile launch of THIS file: trailing_kernel
+  GPTQ_CHECK_HIP(hipMemcpyFromSymbol(out4, HIP_SYMBOL(gemm64_stamps), sizeof(unsigned long long) * 4));
+  return GPTQ_OK;
+}
+#endif
+#ifdef GPTQ_DIAG
 extern "C" int gptq_diag_qb_stamps(unsigned long long* out32) {
   GPTQ_CHECK_HIP(hipMemcpyFromSymbol(out32, HIP_SYMBOL(qb_stamps), sizeof(unsigned long long) * 32));
   return GPTQ_OK;

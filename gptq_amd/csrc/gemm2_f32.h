@@ -69,18 +69,27 @@ __device__ __forceinline__ void stage_store64(float* S, const float r[SGST][4]) 
   }
 }
 
-__device__ __forceinline__ void tile_epilogue64(const f32x16& acc, const Epilogue& ep, int rem_m, int rem_n, int wm,
-                                                int wn, int lane) {
+#ifdef GPTQ_DIAG   // diagnostic library only: s_memtime stamps of workgroup (0, 0) of the last 64-tile launch
+static __device__ unsigned long long gemm64_stamps[8];   // (one copy per translation unit)
+#define G64_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) gemm64_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define G64_STAMP(i) do { } while (0)
+#endif
+// The old values of a read-modify-write epilogue.  gemm_tile64 loads them BEFORE the product: the tile belongs to this
+// workgroup alone, and after the k loop the 16 loads were a whole L2 round trip on the critical path of every small
+// launch (measured: 3.6 k of a rank-128 update's 15.5 k cycles).
+__device__ __forceinline__ void tile_load_old64(float (&old)[16], const Epilogue& ep, int rem_m, int rem_n, int wm, int wn,
+                                                int lane) {
   const bool rmw = ep.mode == EPI_SUB || ep.mode == EPI_AXPBY;
-  float old[16];
-  if (rmw) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int row = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-      const int col = wn * 32 + (lane & 31);
-      old[e] = (row < rem_m && col < rem_n) ? ep.C[(long)row * ep.rs + (long)col * ep.cs] : 0.f;
-    }
+  for (int e = 0; e < 16; ++e) {
+    const int row = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+    const int col = wn * 32 + (lane & 31);
+    old[e] = (rmw && row < rem_m && col < rem_n) ? ep.C[(long)row * ep.rs + (long)col * ep.cs] : 0.f;
   }
+}
+__device__ __forceinline__ void tile_finish64(const f32x16& acc, const float (&old)[16], const Epilogue& ep, int rem_m,
+                                              int rem_n, int wm, int wn, int lane) {
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int row = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
@@ -96,6 +105,13 @@ __device__ __forceinline__ void tile_epilogue64(const f32x16& acc, const Epilogu
     else out = ep.alpha * old[e] + ep.beta * v;
     if (keep) ep.C[(long)row * ep.rs + (long)col * ep.cs] = out;
   }
+  G64_STAMP(3);
+}
+__device__ __forceinline__ void tile_epilogue64(const f32x16& acc, const Epilogue& ep, int rem_m, int rem_n, int wm,
+                                                int wn, int lane) {
+  float old[16];
+  tile_load_old64(old, ep, rem_m, rem_n, wm, wn, lane);
+  tile_finish64(acc, old, ep, rem_m, rem_n, wm, wn, lane);
 }
 
 // acc(64 x 64 tile, this wave's 32 x 32 part) = sum_{k in [k_begin, k_end)} A(m,k) * B(n,k).  The k order of every
@@ -114,6 +130,7 @@ __device__ __forceinline__ void gemm_acc64(const Operand<TA>& a, const Operand<T
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
   float ra[SGST][4], rb[SGST][4];
   const int nk = (k_end - k_begin + GBK - 1) / GBK;
+  G64_STAMP(0);
   if (nk > 0) {
     stage_load64<TA, AKC>(a, k_begin, k_end, ra);
     stage_load64<TB, BKC>(b, k_begin, k_end, rb);
@@ -121,6 +138,9 @@ __device__ __forceinline__ void gemm_acc64(const Operand<TA>& a, const Operand<T
     stage_store64<BKC>(Bs, rb);
   }
   __syncthreads();
+  G64_STAMP(1);
+  // (Tried: operand registers of two stages, i.e. stage kt + 2 in flight while kt + 1 is stored -- the k loop of a rank-128
+  //  update went from 8.3 k to 7.2 k cycles, but the first stage and the epilogue grew by more: 16.3 k instead of 12.2 k.)
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
@@ -143,6 +163,7 @@ __device__ __forceinline__ void gemm_acc64(const Operand<TA>& a, const Operand<T
     __syncthreads();
     cur ^= 1;
   }
+  G64_STAMP(2);
 }
 
 // C_tile(64 x 64) = the product above, combined with memory as `ep` says.
@@ -150,9 +171,11 @@ template <typename TA, typename TB, bool AKC, bool BKC>
 __device__ __forceinline__ void gemm_tile64(const Operand<TA>& a, const Operand<TB>& b, int k_begin, int k_end,
                                             float* smem, const Epilogue& ep) {
   f32x16 acc;
-  gemm_acc64<TA, TB, AKC, BKC>(a, b, k_begin, k_end, smem, acc);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  tile_epilogue64(acc, ep, a.rem, b.rem, wave >> 1, wave & 1, lane);
+  float old[16];
+  tile_load_old64(old, ep, a.rem, b.rem, wave >> 1, wave & 1, lane);     // in flight under the whole product
+  gemm_acc64<TA, TB, AKC, BKC>(a, b, k_begin, k_end, smem, acc);
+  tile_finish64(acc, old, ep, a.rem, b.rem, wave >> 1, wave & 1, lane);
 }
 
 }  // namespace gptq

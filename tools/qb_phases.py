@@ -34,3 +34,12 @@ print(f"{shape}: workgroup 0, cycles")
 for i in range(13):
     print(f"  {names[i] if i < len(names) else i:34s} {t[i + 1] - t[i]:8d}")
 print(f"  {'total':34s} {t[13] - t[0]:8d}")
+out4 = (C.c_ulonglong * 4)()
+for fname, what in (("gptq_diag_trailing_stamps", "last trailing_kernel launch (64 x 64 tile, workgroup 0)"),
+                    ("gptq_diag_chain64_stamps", "last 64-tile launch of the chain (rtilde / syrk / panel, workgroup 0)")):
+    f = getattr(lib, fname)
+    f.restype = C.c_int
+    f.argtypes = [C.POINTER(C.c_ulonglong)]
+    assert f(out4) == 0
+    u = [out4[i] for i in range(4)]
+    print(f"{what}: first stage {u[1] - u[0]}, k loop {u[2] - u[1]}, epilogue {u[3] - u[2]}, total {u[3] - u[0]} cycles")
