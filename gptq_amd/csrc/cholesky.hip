@@ -338,7 +338,7 @@ constexpr size_t POTRF_LDS = sizeof(float) * (NB * (NB + 1) + 32 * 33 + 32);
 __global__ __launch_bounds__(GEMM_THREADS) void panel_kernel(float* __restrict__ A,
                                                              const float* __restrict__ Linv, int Cp, int kb) {
   critical_path_priority();
-  __shared__ __attribute__((aligned(16))) float smem[GEMM64_LDS_FLOATS];
+  __shared__ __attribute__((aligned(16))) float smem[GEMM64X2_LDS_FLOATS];
   const int tm = kb + 1 + (blockIdx.x >> 1), sm = blockIdx.x & 1;
   float* P = A + ((long)tm * NB + 64 * sm) * Cp + (long)kb * NB;
   const float* D = Linv + (long)kb * NB * Cp + (long)kb * NB;
@@ -346,8 +346,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void panel_kernel(float* __restrict__
   Operand<float> b0{D, Cp, 1, 64, true};
   Operand<float> b1{D + 64L * Cp, Cp, 1, 64, true};
   f32x16 acc0, acc1;
-  gemm_acc64<float, float, true, true>(a, b0, 0, NB, smem, acc0);
-  gemm_acc64<float, float, true, true>(a, b1, 0, NB, smem, acc1);     // (ends with a barrier: all reads of P are done)
+  // both halves in ONE pass over P; inv(L_kk) is lower triangular: its first 64 rows end at k = 64
+  gemm_acc64x2<float, float, true, true>(a, b0, b1, 0, 64, NB, smem, acc0, acc1);   // (ends with a barrier: all reads of P are done)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   tile_epilogue64(acc0, Epilogue{P, Cp, 1, EPI_STORE, TRI_ALL, 0.f, 0.f}, 64, 64, wave >> 1, wave & 1, lane);
   tile_epilogue64(acc1, Epilogue{P + 64, Cp, 1, EPI_STORE, TRI_ALL, 0.f, 0.f}, 64, 64, wave >> 1, wave & 1, lane);

@@ -166,6 +166,72 @@ __device__ __forceinline__ void gemm_acc64(const Operand<TA>& a, const Operand<T
   G64_STAMP(2);
 }
 
+// Two products that share the A operand:  acc0 = A B0^T over [k_begin, k0_end),  acc1 = A B1^T over [k_begin, k_end),
+// k0_end <= k_end (a multiple of GBK past k_begin) -- the panel solve's two 64-column halves, of which the first needs only
+// the first half of the triangular factor's k range.  One pass over A instead of two, one pipeline fill instead of two.
+// `smem` must hold GEMM64X2_LDS_FLOATS floats.  Same ascending k order per output element as gemm_acc64.
+constexpr int GEMM64X2_LDS_FLOATS = 3 * 2 * GBK * 68;
+template <typename TA, typename TB, bool AKC, bool BKC>
+__device__ __forceinline__ void gemm_acc64x2(const Operand<TA>& a, const Operand<TB>& b0, const Operand<TB>& b1,
+                                             int k_begin, int k0_end, int k_end, float* smem, f32x16& acc0, f32x16& acc1) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  float* As = smem;
+  float* B0s = smem + 2 * GBK * 68;
+  float* B1s = smem + 4 * GBK * 68;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+  float ra[SGST][4], rb0[SGST][4], rb1[SGST][4];
+  const int nk = (k_end - k_begin + GBK - 1) / GBK;
+  const int nk0 = (k0_end - k_begin + GBK - 1) / GBK;               // stages in which acc0 takes part
+  if (nk > 0) {
+    stage_load64<TA, AKC>(a, k_begin, k_end, ra);
+    if (nk0 > 0) stage_load64<TB, BKC>(b0, k_begin, k0_end, rb0);
+    stage_load64<TB, BKC>(b1, k_begin, k_end, rb1);
+    stage_store64<AKC>(As, ra);
+    if (nk0 > 0) stage_store64<BKC>(B0s, rb0);
+    stage_store64<BKC>(B1s, rb1);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk, more0 = kt + 1 < nk0;             // (workgroup-uniform)
+    if (more) {
+      stage_load64<TA, AKC>(a, k_begin + (kt + 1) * GBK, k_end, ra);
+      if (more0) stage_load64<TB, BKC>(b0, k_begin + (kt + 1) * GBK, k0_end, rb0);
+      stage_load64<TB, BKC>(b1, k_begin + (kt + 1) * GBK, k_end, rb1);
+    }
+    constexpr int LDA = LdsStride64<AKC>::v, LDB = LdsStride64<BKC>::v;
+    const float* Ac = As + cur * GBK * 68 + wm * 32 + (lane & 31);
+    const float* B0c = B0s + cur * GBK * 68 + wn * 32 + (lane & 31);
+    const float* B1c = B1s + cur * GBK * 68 + wn * 32 + (lane & 31);
+    if (kt < nk0) {
+#pragma unroll
+      for (int kk = 0; kk < GBK; kk += 2) {
+        const int k = kk + (lane >> 5);
+        const float av = Ac[k * LDA];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, B0c[k * LDB], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, B1c[k * LDB], acc1, 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < GBK; kk += 2) {
+        const int k = kk + (lane >> 5);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[k * LDA], B1c[k * LDB], acc1, 0, 0, 0);
+      }
+    }
+    if (more) {
+      stage_store64<AKC>(As + (cur ^ 1) * GBK * 68, ra);
+      if (more0) stage_store64<BKC>(B0s + (cur ^ 1) * GBK * 68, rb0);
+      stage_store64<BKC>(B1s + (cur ^ 1) * GBK * 68, rb1);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
 // C_tile(64 x 64) = the product above, combined with memory as `ep` says.
 template <typename TA, typename TB, bool AKC, bool BKC>
 __device__ __forceinline__ void gemm_tile64(const Operand<TA>& a, const Operand<TB>& b, int k_begin, int k_end,
