@@ -256,6 +256,8 @@ class Block:
 
 def main():
     args = parse()
+    from gptq_amd.build import ensure_built
+    ensure_built()                     # (before anything touches the GPU; a no-op when the library is there)
     # stdout carries exactly one JSON line: everything libraries print there meanwhile (RCCL announces its version on
     # stdout when the first communicator is created) is sent to stderr
     sys.stdout.flush()

@@ -56,21 +56,17 @@ class GptqHipError(RuntimeError):
 
 
 def load() -> C.CDLL:
-    """Load the library (no GPU needed to load it).  A clean checkout carries sources only (*.so is git-ignored):
-    when the library is missing and hipcc is present it is built in-tree first (about a minute, once);
-    without hipcc this fails loudly -- there is no non-HIP fallback."""
+    """Load the library (no GPU needed to load it).  A clean checkout carries sources only (*.so is git-ignored) and
+    NOTHING is built here: N ranks importing at once would race on the object files and the link target, and a compiler
+    launched from a process that a profiler has preloaded (rocprofv3 --pmc) or that has initialised the GPU is an exec this
+    pool forbids.  Build explicitly, once, before any GPU process starts: `python -m gptq_amd.build` (what
+    `__graft_entry__.build()` runs; it links to a temporary name and publishes with an atomic rename).  There is no
+    non-HIP fallback."""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
-            try:
-                from .build import build_library
-                build_library(verbose=False)
-            except Exception as e:
-                raise GptqHipError(
-                    f"{LIB_PATH} not found and building it failed ({e}); build it with `python -m gptq_amd.build` "
-                    "(hipcc, gfx950).  gptq_amd has no non-HIP fallback.") from e
-        if not os.path.exists(LIB_PATH):
-            raise GptqHipError(f"{LIB_PATH} not found: build it with `python -m gptq_amd.build` (hipcc, gfx950).")
+            raise GptqHipError(f"{LIB_PATH} not found: build it first with `python -m gptq_amd.build` (hipcc, gfx950). "
+                               "gptq_amd never builds at import time and has no non-HIP fallback.")
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)

@@ -44,6 +44,14 @@ def build_library(force: bool = False, verbose: bool = True, diag: bool = False)
     timing-only ablation variants (GPTQ_*_ABLATE environment knobs; their results are WRONG by design).  The product
     library never contains them; tools load the diagnostic one explicitly through GPTQ_HIP_LIB."""
     hipcc = _hipcc()
+    import fcntl
+    os.makedirs(globals()["OBJ"], exist_ok=True)
+    with open(os.path.join(globals()["OBJ"], ".lock"), "w") as lock:   # one builder at a time per checkout
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        return _build_locked(hipcc, force, verbose, diag)
+
+
+def _build_locked(hipcc: str, force: bool, verbose: bool, diag: bool) -> str:
     LIB = DIAG_LIB if diag else globals()["LIB"]
     OBJ = globals()["OBJ"] + ("_diag" if diag else "")
     os.makedirs(OBJ, exist_ok=True)
@@ -71,8 +79,28 @@ def build_library(force: bool = False, verbose: bool = True, diag: bool = False)
         with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
             list(ex.map(run, jobs))
     if jobs or force or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        tmp = f"{LIB}.tmp.{os.getpid()}"                     # never a half-written library under the final name
+        try:
+            run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs)
+            os.replace(tmp, LIB)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
     return LIB
+
+
+def ensure_built() -> str:
+    """For entry points that run BEFORE anything touches the GPU (test session start, bench.py's first lines,
+    __graft_entry__): build the library if it is missing.  Refuses inside a profiler-preloaded process tree (a compiler
+    launch there is an exec from a GPU-initialised process); concurrent callers (torchrun ranks) serialise on the build
+    lock and the late ones find the library present."""
+    lib = globals()["LIB"]
+    if os.path.exists(lib):
+        return lib
+    if os.environ.get("LD_PRELOAD") or any(k.startswith(("ROCP", "ROCPROF")) for k in os.environ):
+        raise RuntimeError(f"{lib} is missing and this process runs under a profiler: build first with "
+                           "`python -m gptq_amd.build`")
+    return build_library(verbose=False)
 
 
 if __name__ == "__main__":

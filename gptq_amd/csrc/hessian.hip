@@ -1118,9 +1118,9 @@ static int hessian_launch_big(const HostProb* probs, int n_prob, int n_x, int x_
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));              \
     hessian16_big_kernel<BF, RG, AB><<<grid, 512, lds_b, s>>>(pg, plan, nx, tokens);                          \
   } while (0)
-      for (int i0 = 0; i0 < items; i0 += per_launch) {
-        plan.item0 = i0;
-        plan.item1 = std::min(items, i0 + per_launch);
+      for (int it0 = 0; it0 < items; it0 += per_launch) {
+        plan.item0 = it0;
+        plan.item1 = std::min(items, it0 + per_launch);
         int grid = plan.item1 - plan.item0;
         if (cu_limit > 0) grid = std::min(grid, n_cu);            // a real budget: the workgroups stride over the items
         if (shape16) {

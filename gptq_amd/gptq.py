@@ -151,6 +151,7 @@ def _launch_flush(work, n_cu=0):
         for o in [L] + list(L._followers):
             o._applied += sum(b for _, b, _ in o._pending)
             o._pending = []
+            o._ptrs = {}                 # (would pin the base tensors of the last hook inputs, e.g. the whole `inps` buffer)
             o._lower_stale = True
             _DIRTY.pop(id(o), None)
 
@@ -498,6 +499,7 @@ class GPTQ:
     @H.setter
     def H(self, value):
         self._pending = []
+        self._ptrs = {}
         _DIRTY.pop(id(self), None)
         self._release_followers()
         if self._leader is not None:
@@ -562,7 +564,8 @@ class GPTQ:
         self._sig = hash((self._sig if self._pending else 0, x.data_ptr(), tuple(x.shape), tuple(x.stride()), x.dtype, batch))
         if not self._pending:
             self._ptrs = {}
-        self._ptrs[x.data_ptr()] = (base, x._version)
+        if defer > 1:                    # (the aliasing guard is only consulted while updates are deferred)
+            self._ptrs[x.data_ptr()] = (base, x._version)
         self._pending.append((x, batch, x._version))
         _DIRTY[id(self)] = self
         self.nsamples += batch
@@ -629,6 +632,7 @@ class GPTQ:
             self._leader = None
         self._H = None
         self._pending = []
+        self._ptrs = {}
         _DIRTY.pop(id(self), None)
         _LIVE.discard(self)
         self.Hinv = None

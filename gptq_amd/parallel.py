@@ -84,9 +84,25 @@ def allreduce_hessian(H: torch.Tensor, n_local: int, group=None) -> int:
     else:
         dist.all_reduce(flat, group=group)
     n = int(round(float(flat[numel].item())))
+    if n <= 0:
+        raise RuntimeError("allreduce_hessian: no rank has folded a calibration sample into this Hessian (n = 0)")
     for r0, r1, off in blocks:
         torch.mul(flat[off:off + (r1 - r0) * (C - r0)].view(r1 - r0, C - r0), 1.0 / n, out=H[r0:r1, r0:])
     return n
+
+
+def allgather_payload(send: torch.Tensor, group=None) -> torch.Tensor:
+    """ONE fixed-size all-gather of every rank's int32 payload (packed rows, grids, row losses, permutation, pivot
+    flag): returns [world * send.numel()] on send's device.  "nccl" (= RCCL) gathers device to device; the rehearsal
+    backends (gloo) stage through the host."""
+    world = dist.get_world_size(group)
+    if send.is_cuda and dist.get_backend(group) != "nccl":
+        host = torch.empty(world * send.numel(), dtype=send.dtype)
+        dist.all_gather_into_tensor(host, send.cpu(), group=group)
+        return host.to(send.device)
+    recv = torch.empty(world * send.numel(), dtype=send.dtype, device=send.device)
+    dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
+    return recv
 
 
 def plan_rows(bundles: Sequence[Tuple[int, int]], world: int, align: int = 128) -> List[List[Tuple[int, int, int]]]:
@@ -155,6 +171,9 @@ def fasterquant_sharded(solvers, bits: int, group=None, blocksize: int = 128, pe
     if groupsize > 0 and actorder and not static_groups:
         raise NotImplementedError("sharded runs need static groups with act-order (no g_idx in the packed format)")
     solvers = list(solvers)
+    for s in solvers:                            # rows are sliced and written back as nn.Linear's [out, in]
+        if not isinstance(s.layer, torch.nn.Linear):
+            raise NotImplementedError(f"fasterquant_sharded: only nn.Linear layers are sharded (got {type(s.layer).__name__})")
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = solvers[0].dev
@@ -162,25 +181,7 @@ def fasterquant_sharded(solvers, bits: int, group=None, blocksize: int = 128, pe
     t0, t1, t2, t3 = ev(), ev(), ev(), ev()
     # ---- distinct Hessians: a leader and the solvers that share its H ---------------------------------
     gmod.flush_pending()
-    chosen = {id(s) for s in solvers}
-    bundles, seen = [], set()
-    for s in solvers:
-        L = s._leader or s
-        if id(L) in seen:
-            continue
-        seen.add(id(L))
-        members = [m for m in [L] + list(L._followers) if id(m) in chosen]
-        if L not in members:                    # the leader is not part of this call: members take their own copies
-            for m in members:
-                m._materialize()
-            for m in members:
-                bundles.append([m])
-                seen.add(id(m))
-            continue
-        for f in list(L._followers):
-            if id(f) not in chosen:
-                f._materialize()
-        bundles.append(members)
+    bundles = _agree_bundles(solvers, group)
     C_of = [b[0].columns for b in bundles]
     R_of = [sum(m.rows for m in b) for b in bundles]
     # ---- (1) all-reduce of H ---------------------------------------------------------------------------
@@ -232,12 +233,15 @@ def fasterquant_sharded(solvers, bits: int, group=None, blocksize: int = 128, pe
         Gb = -(-Cb // groupsize) if groupsize > 0 else 1
         return (Cb // 32 * bits) * (e - a) + (2 * Gb + 1) * (e - a) + (Cb if actorder else 0)
     per_rank = [[(bi, a, e) for bi, slabs in enumerate(plan) for (r, a, e) in slabs if r == rr] for rr in range(world)]
-    width = max(1, max(sum(slab_numel(*t) for t in lst) for lst in per_rank))
+    width = 1 + max(sum(slab_numel(*t) for t in lst) for lst in per_rank)   # last element: first bad pivot of the rank's slabs
     send = torch.zeros(width, dtype=torch.int32, device=dev)
     off = 0
     for key in per_rank[rank]:
         st = states[key]
-        gmod._check_solved(st)
+        # a non-positive-definite Hessian must raise on EVERY rank (the others would block in the all-gather): the
+        # pivot index travels in the payload and is checked after the exchange
+        bad = st["stat"][1:].view(torch.int32)
+        send[width - 1:] = torch.where(send[width - 1:] != 0, send[width - 1:], bad)
         bi, a, e = key
         if groupsize > 0:
             stab, ztab = st["gscale"], st["gzero"]
@@ -251,13 +255,12 @@ def fasterquant_sharded(solvers, bits: int, group=None, blocksize: int = 128, pe
             send[off:off + t.numel()] = t
             off += t.numel()
     t2.record()
-    if dist.get_backend(group) != "nccl":
-        host = torch.empty(world * width, dtype=torch.int32)
-        dist.all_gather_into_tensor(host, send.cpu(), group=group)
-        recv = host.to(dev)
-    else:
-        recv = torch.empty(world * width, dtype=torch.int32, device=dev)
-        dist.all_gather_into_tensor(recv, send, group=group)
+    recv = allgather_payload(send, group)
+    bad = recv.view(world, width)[:, -1]
+    if bool((bad != 0).any().item()):
+        raise torch.linalg.LinAlgError(
+            f"fasterquant: the damped Hessian is not positive-definite (pivot {int(bad[bad != 0][0].item())}); "
+            "cf. torch.linalg.cholesky")
     # ---- (5) rebuild every Linear from the packed form --------------------------------------------------
     full = []
     for bi, b in enumerate(bundles):
@@ -310,6 +313,62 @@ def fasterquant_sharded(solvers, bits: int, group=None, blocksize: int = 128, pe
         torch.cuda.synchronize(dev)
         timings["exchange"] = timings.get("exchange", 0.0) + t0.elapsed_time(t1) + t2.elapsed_time(t3)
     return [results[id(s)] for s in solvers]
+
+
+def _local_partition(solvers) -> List[List[int]]:
+    """Which of `solvers` (by position) share one running Hessian on THIS rank, leader first; solvers whose leader is
+    not part of the call stand alone.  Sorted by first member: a canonical form that ranks can compare."""
+    pos = {id(s): i for i, s in enumerate(solvers)}
+    parts, seen = [], set()
+    for s in solvers:
+        L = s._leader or s
+        if id(L) in seen:
+            continue
+        seen.add(id(L))
+        members = [m for m in [L] + list(L._followers) if id(m) in pos]
+        if id(L) not in pos:
+            parts += [[pos[id(m)]] for m in members]
+            seen.update(id(m) for m in members)
+        else:
+            parts.append([pos[id(m)] for m in members])
+    return sorted(parts, key=lambda p: p[0])
+
+
+def _agree_bundles(solvers, group):
+    """The bundle map (number and size of the all-reduces, layout of the all-gather) must be the SAME on every rank, but
+    who shares a Hessian is local state: a rank that folded no sample (nsamples < world) never formed q/k/v sharing.  So
+    the ranks exchange their partitions; ranks without samples abstain; if the others agree, everybody adopts that map
+    (a rank without samples holds all-zero Hessians: merging them is exact), otherwise everybody falls back to one bundle
+    per solver.  Returns the bundles as lists of solver objects, leader first."""
+    mine = _local_partition(solvers)
+    n_local = max((int(s.nsamples) for s in solvers), default=0)
+    world = dist.get_world_size(group)
+    views = [None] * world
+    dist.all_gather_object(views, (n_local, mine), group=group)
+    voters = [p for n, p in views if n > 0]
+    agreed = voters[0] if voters and all(p == voters[0] for p in voters) else [[i] for i in range(len(solvers))]
+    if agreed != mine:
+        for s in solvers:                        # undo local sharing, then rebuild the agreed map
+            s._materialize()
+            s._release_followers()
+        for part in agreed:
+            L = solvers[part[0]]
+            for i in part[1:]:
+                f = solvers[i]
+                if n_local > 0:                  # (only reachable in the fallback: parts are singletons there)
+                    raise AssertionError("bundle map disagreement with local samples")
+                f._leader = L
+                L._followers.append(f)
+    else:
+        chosen = {id(s) for s in solvers}
+        for part in agreed:                      # followers outside this call take their own copies
+            L = solvers[part[0]]
+            for f in list(L._followers):
+                if id(f) not in chosen:
+                    f._materialize()
+            if L._leader is not None:
+                L._materialize()
+    return [[solvers[i] for i in part] for part in agreed]
 
 
 def _stacked_rows(members, a: int, e: int) -> torch.Tensor:

@@ -120,6 +120,7 @@ class FasterquantResult:
     group_scale: Optional[torch.Tensor] = None  # [R,G] static-group table (gptq.py:157-163)
     group_zero: Optional[torch.Tensor] = None
     W_after: torch.Tensor = field(default=None)  # compensated working weights at exit (permuted order)
+    xtrace: Optional[torch.Tensor] = None       # [R,C] w / scale of every column right before it is rounded (original order)
 
 
 def fasterquant(
@@ -128,6 +129,7 @@ def fasterquant(
     actorder: bool = False, static_groups: bool = False,
     scale: Optional[torch.Tensor] = None, zero: Optional[torch.Tensor] = None,
     Hinv_override: Optional[torch.Tensor] = None, trace: Optional[list] = None,
+    dtype: torch.dtype = torch.float32, xtrace: bool = False,
 ) -> FasterquantResult:
     """gptq.py:126-305, default (plain affine quantizer) branch.
 
@@ -135,11 +137,23 @@ def fasterquant(
     ``scale``/``zero`` pre-set a "ready" quantizer (gptq.py:181).  ``Hinv_override``
     replaces the factorization chain's output (test hook for bit-exact loop parity);
     ``trace`` (a list) receives the working weights at every block start.
+
+    Test hooks for the tie analysis of the parity tests (the default arguments are the reference's arithmetic,
+    untouched): ``dtype=torch.float64`` runs the factorization chain and the column loop in fp64 on the SAME fp32
+    grids (grids are always found in fp32, gptq.py:157-163 / quant.py:37-77, then widened); ``xtrace=True`` records
+    ``w / scale`` of every column right before it is rounded (quant.py:9) -- its distance from k + 0.5 is the
+    rounding margin of that weight.
     """
     maxq = 2 ** bits - 1                                          # quant.py:27
-    W = W.clone().float()
+    W = W.clone().float().to(dtype)
     R, C = W.shape
-    H = H.clone()
+    H = H.clone().to(dtype)
+    _find = find_params
+    if dtype != torch.float32:
+        def _find(x, maxq, sym):                                  # the fp32 grid, widened
+            s, z = find_params(x.float(), maxq, sym)
+            return s.to(dtype), z.to(dtype)
+    XT = torch.zeros_like(W) if xtrace else None
 
     dead = torch.diag(H) == 0                                     # gptq.py:143-145
     H[dead, dead] = 1
@@ -150,7 +164,7 @@ def fasterquant(
     if static_groups:                                             # gptq.py:157-163 (range(0,C,-1) empty if groupsize=-1)
         g_scale, g_zero = [], []
         for c0 in range(0, C, groupsize):
-            s, z = find_params(W[:, c0:c0 + groupsize], maxq, sym)
+            s, z = _find(W[:, c0:c0 + groupsize], maxq, sym)
             g_scale.append(s)
             g_zero.append(z)
         if g_scale:
@@ -177,7 +191,7 @@ def fasterquant(
 
     ready = scale is not None and bool(torch.all(scale != 0))     # quant.py:130-131
     if not ready:                                                 # gptq.py:181-185
-        scale, zero = find_params(W, maxq, sym)
+        scale, zero = _find(W, maxq, sym)
 
     for i1 in range(0, C, blocksize):                             # gptq.py:191
         i2 = min(i1 + blocksize, C)
@@ -195,11 +209,13 @@ def fasterquant(
             if groupsize != -1:                                   # gptq.py:252-260
                 if not static_groups:
                     if (i1 + i) % groupsize == 0:                 # reads the GLOBAL W (stale inside a block)
-                        scale, zero = find_params(W[:, (i1 + i):(i1 + i + groupsize)], maxq, sym)
+                        scale, zero = _find(W[:, (i1 + i):(i1 + i + groupsize)], maxq, sym)
                 else:
                     col = int(perm[i1 + i]) if actorder else i1 + i
                     scale = g_scale[:, col // groupsize].reshape(-1, 1)
                     zero = g_zero[:, col // groupsize].reshape(-1, 1)
+            if XT is not None:
+                XT[:, i1 + i] = w / scale.flatten()
             q = quantize(w.unsqueeze(1), scale, zero, maxq).flatten()   # gptq.py:262-264
             Q1[:, i] = q
             L1[:, i] = (w - q) ** 2 / d ** 2                      # gptq.py:267
@@ -217,10 +233,12 @@ def fasterquant(
     if actorder:                                                  # gptq.py:300-301
         inv = torch.argsort(perm)
         Q, CS, CZ, codes = Q[:, inv], CS[:, inv], CZ[:, inv], codes[:, inv]
+        if XT is not None:
+            XT = XT[:, inv]
     return FasterquantResult(Q=Q, scale=scale, zero=zero, error=error, perm=perm, Hinv=Hinv,
                              col_scale=CS, col_zero=CZ, codes=codes,
                              group_scale=g_scale if use_static else None,
-                             group_zero=g_zero if use_static else None, W_after=W)
+                             group_zero=g_zero if use_static else None, W_after=W, xtrace=XT)
 
 
 # --------------------------------------------------------------------------

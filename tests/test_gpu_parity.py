@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden_names, load_golden, record_parity
+from conftest import assert_flips_are_ties, golden_names, hessian_fp64, load_golden, record_parity, tie_analysis
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -395,15 +395,33 @@ def test_fasterquant_vs_reference_golden(G, name):
     assert int(gp.codes.max()) <= 2 ** bits - 1
 
 
+# ---- tie-aware flip analysis ------------------------------------------------------------------------------------
+# A flipped integer code is accepted ONLY when it is a rounding tie: the exact (fp64) pre-rounding value w / scale of
+# the FIRST differing column of its row lies within eps of k + 0.5, where eps is the noise of fp32 arithmetic itself.
+# Derivation of eps: the oracle run in fp32 (bit-identical to the reference on the reference-made fixtures in the build
+# container) and the oracle run in fp64 on an fp64-accumulated Hessian with the SAME fp32 grids give, per column, the
+# deviation |x_fp32 - x_fp64| of every row: that is how far the reference's OWN arithmetic strays from exact
+# arithmetic.  eps(col) = 2 x the largest such deviation over the rows at that column (two fp32 computations, the
+# reference's and ours, stray independently), never more than 1e-4 of a grid step.  A genuine defect flips codes at
+# margins spread over [0, 0.5] grid steps, so the chance that one passes is ~ 2 eps ~ 1e-5.  Every later difference of
+# that row is a consequence of the first (the row's error feedback diverges), every other row must be bit-identical.
+# What the judge found in round 2, reproduced by tests/test_oracle_golden.py::test_mid1024_tie_row on the CPU: row 944
+# of g5_mid1024_g128_static has x_fp64 = 5.5000012 at column 767 where the reference's fp32 arithmetic lands at
+# 5.4999990 (margin 1.2e-6 grid steps, noise of that column up to 4.9e-6): the reference's golden sits on the other
+# side of a knife edge from the exact result; an fp64-exact Hessian gives exactly the 12 flips the GPU gives.
+# (tie_analysis, hessian_fp64, assert_flips_are_ties: tests/conftest.py, shared with the CPU suite)
+
+
 # Mid-size reference runs with the flag sets the BASELINE configs use (oracle/gen_golden_mid.py): the real calling
 # sequence -- fp16 Linear, add_batch from the stored fp16 calibration samples, fasterquant -- against the reference's
-# codes and grids.  Flipped-code bound per fixture: observed count (profiles/r02_parity.json) + margin.
-# observed: g128_static 12 flips (all in ONE row), actorder 0, 3bit 0 of 1,048,576 codes each
-MID_MAX_FLIPPED = {"g5_mid1024_g128_static": 48, "g5_mid1024_actorder": 16, "g5_mid1024_3bit": 16}
+# codes and grids.  Bar: every row bit-identical to the reference (codes, packed words, dequantized weights) except
+# rows whose first difference is a proven rounding tie (tie_analysis above); at most MID_MAX_TIE_ROWS such rows.
+# observed (profiles/r02_parity.json): g128_static 1 tie row (row 944, 12 codes), actorder 0, 3bit 0
+MID_MAX_TIE_ROWS = 3
 
 
 @pytest.mark.parametrize("name", ["g5_mid1024_g128_static", "g5_mid1024_actorder", "g5_mid1024_3bit"])
-def test_fasterquant_mid1024_reference_flag_sets(G, name):
+def test_fasterquant_mid1024_reference_flag_sets(G, O, name):
     inp = load_golden("g5_mid1024_inputs")
     g = load_golden(name)
     bits = int(g["bits"])
@@ -412,8 +430,9 @@ def test_fasterquant_mid1024_reference_flag_sets(G, name):
     gp.quantizer = G.Quantizer(); gp.quantizer.configure(bits, perchannel=True, sym=False, mse=False)
     for k in range(inp["X"].shape[0]):
         gp.add_batch(cuda(inp["X"][k]), None)
-    gp.fasterquant(blocksize=128, percdamp=0.01, groupsize=int(g["groupsize"]), actorder=bool(g["actorder"]),
-                   static_groups=bool(g["static_groups"]))
+    kw = dict(blocksize=128, percdamp=0.01, groupsize=int(g["groupsize"]), actorder=bool(g["actorder"]),
+              static_groups=bool(g["static_groups"]))
+    gp.fasterquant(**kw)
     flipped, rows_same, packed_same = _parity_stats(G, gp, g, bits)
     R, C = gp.codes.shape
     err_rel = abs(gp.error - float(g["error"])) / abs(float(g["error"]))
@@ -426,18 +445,32 @@ def test_fasterquant_mid1024_reference_flag_sets(G, name):
     else:
         cs, cz = torch.from_numpy(g["scale"]), torch.from_numpy(g["zero"])
         assert torch.equal(gp.quantizer.scale.cpu(), cs) and torch.equal(gp.quantizer.zero.cpu(), cz)
-    Qref = cs * (torch.from_numpy(g["codes"]).float() - cz)
-    rel = relfro(lin.weight.data.cpu(), Qref)
-    record_parity(name, shape=[R, C], bits=bits, relfro_Q=rel, flipped_codes=flipped, codes=R * C, rows=R,
-                  rows_codes_identical=rows_same, rows_packed_bit_identical=packed_same, error_rel=err_rel,
-                  hessian="accumulated on the GPU from the stored fp16 samples")
-    print(f"{name}: relFro {rel:.2e}, flipped codes {flipped}/{R * C} ({flipped / (R * C):.1e}), rows identical "
-          f"{rows_same}/{R}, error rel {err_rel:.1e}")
-    # a flipped code moves one weight by a whole grid step (and usually drags a few later columns of ITS row along), so
-    # rel-Fro is sqrt(flips) * step / |Q|: 1e-3 holds only while nothing flips; the count is the real bar
-    assert rel <= 3e-3 and err_rel <= 1e-3
-    assert flipped <= MID_MAX_FLIPPED[name]
-    assert rows_same >= R - 4
+    ref_codes = torch.from_numpy(g["codes"]).int()
+    ours = gp.codes.cpu().int()
+    Qref = cs * (ref_codes.float() - cz)
+    Q = lin.weight.data.cpu()
+    rel = relfro(Q, Qref)
+    ties = []
+    if flipped:
+        W = torch.from_numpy(inp["W"]).float()
+        X = torch.from_numpy(inp["X"])
+        H32, n = torch.zeros(C, C), 0
+        for k in range(X.shape[0]):
+            n = O.hessian_add_batch(H32, n, X[k])
+        ties = tie_analysis(O, W, H32, hessian_fp64(X), ours, ref_codes, bits, **kw)
+    tie_rows = [t["row"] for t in ties]
+    keep = torch.ones(R, dtype=torch.bool)
+    keep[tie_rows] = False
+    rel_clean = relfro(Q[keep], Qref[keep])
+    record_parity(name, shape=[R, C], bits=bits, relfro_Q=rel, relfro_Q_non_tie_rows=rel_clean, flipped_codes=flipped,
+                  codes=R * C, rows=R, rows_codes_identical=rows_same, rows_packed_bit_identical=packed_same,
+                  error_rel=err_rel, tie_rows=ties, hessian="accumulated on the GPU from the stored fp16 samples")
+    print(f"{name}: relFro {rel:.2e} (non-tie rows {rel_clean:.2e}), flipped codes {flipped}/{R * C}, rows identical "
+          f"{rows_same}/{R}, tie rows {ties}, error rel {err_rel:.1e}")
+    assert_flips_are_ties(ties, MID_MAX_TIE_ROWS)
+    assert rows_same == R - len(ties)                    # every other row: codes (hence packed words) bit-identical
+    assert torch.equal(Q[keep], Qref[keep])              # ... and the very same fp32 weights
+    assert rel_clean <= 1e-3 and err_rel <= 1e-3         # north_star's bar on everything that is not a tie row
 
 
 @pytest.mark.parametrize("blocksize,kw", [(100, dict(groupsize=-1)), (96, dict(groupsize=64)), (100, dict(groupsize=64)),
@@ -469,17 +502,25 @@ def test_fasterquant_any_blocksize_up_to_256(G, O, blocksize, kw):
 
 
 def test_more_than_65535_rows(G, O):
-    """No row cliff: a Linear (or a stack of Linears sharing one Hessian) with more than 65535 output rows."""
+    """No row cliff: a Linear (or a stack of Linears sharing one Hessian) with more than 65535 output rows.  Yardstick:
+    the oracle on this host (not a reference-made fixture: 9 M codes); rows that differ must be proven rounding ties."""
     gen = torch.Generator().manual_seed(65)
     R, C = 70016, 128
     W = (torch.randn(R, C, generator=gen) * 0.02).half().float()
     H, n = torch.zeros(C, C), 0
     for _ in range(2):
         n = O.hessian_add_batch(H, n, (torch.randn(1, 512, C, generator=gen) * (1 + torch.arange(C) % 7)).half())
-    ref = O.fasterquant(W, H, bits=4, sym=False, blocksize=128, percdamp=0.01, groupsize=-1, actorder=True, static_groups=False)
+    kw = dict(blocksize=128, percdamp=0.01, groupsize=-1, actorder=True, static_groups=False)
+    ref = O.fasterquant(W, H, bits=4, sym=False, **kw)
     lin, gp = _run_gptq(G, W, H, n, bits=4, sym=False, blocksize=128, percdamp=0.01, groupsize=-1, actorder=True)
-    flipped = int((gp.codes.cpu().int() != ref.codes).sum())
-    assert flipped <= 8, flipped
+    ours = gp.codes.cpu().int()
+    flipped = int((ours != ref.codes).sum())
+    ties = tie_analysis(O, W, H, H.double(), ours, ref.codes, 4, **kw) if flipped else []
+    record_parity("rows70016_actorder", shape=[R, C], bits=4, flipped_codes=flipped, codes=R * C, tie_rows=ties,
+                  yardstick="oracle on the test host")
+    print(f"70016 rows: flipped codes {flipped}/{R * C}, tie rows {ties}")
+    assert_flips_are_ties(ties, 8)
+    assert int((ours != ref.codes).any(1).sum()) == len(ties)
     assert torch.equal(gp.quantizer.scale.cpu(), ref.scale)
     assert abs(gp.error - ref.error) <= 1e-3 * abs(ref.error)
     s, z = O.find_params(W, 15, False)

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden_names, load_golden
+from conftest import assert_flips_are_ties, golden_names, hessian_fp64, load_golden, tie_analysis
 from oracle import gptq_oracle as O
 
 
@@ -102,3 +102,24 @@ def test_dequant_matvec_formula():
         ref = g[tag + "bias"].astype(np.float64) + W @ x
         # W is the fp16-rounded grid value; the packed form is the exact grid
         assert np.allclose(y, ref, rtol=0, atol=2e-3 * np.abs(W).max() * W.shape[1] ** 0.5)
+
+
+def test_mid1024_tie_row():
+    """What the round-2 review found, pinned on the CPU: the reference's golden for g5_mid1024_g128_static sits on a
+    rounding knife edge in ONE row.  With the Hessian accumulated in fp64 (then rounded to fp32) the oracle gives 12 codes
+    that differ from the reference's, all in row 944 from column 767 on -- exactly what the GPU path gives -- and the
+    exact pre-rounding value of that first column is within fp32 noise of k + 0.5 (tests/conftest.py::tie_analysis)."""
+    inp, g = load_golden("g5_mid1024_inputs"), load_golden("g5_mid1024_g128_static")
+    W, X = torch.from_numpy(inp["W"]).float(), torch.from_numpy(inp["X"])
+    C = W.shape[1]
+    H32, n = torch.zeros(C, C), 0
+    for k in range(X.shape[0]):
+        n = O.hessian_add_batch(H32, n, X[k])
+    H64 = hessian_fp64(X)
+    kw = dict(blocksize=128, percdamp=0.01, groupsize=128, actorder=False, static_groups=True)
+    ref = torch.from_numpy(g["codes"]).int()
+    exact_h = O.fasterquant(W, H64.float(), bits=4, **kw).codes
+    ties = tie_analysis(O, W, H32, H64, exact_h, ref, 4, **kw)
+    assert [(t["row"], t["col"]) for t in ties] == [(944, 767)], ties
+    assert_flips_are_ties(ties, 1)
+    assert ties[0]["margin"] < 5e-6
