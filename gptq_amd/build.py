@@ -16,13 +16,16 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgptq_hip.so")
 DIAG_LIB = os.path.join(HERE, "libgptq_hip_diag.so")
 OBJ = os.path.join(HERE, "csrc", "_obj")
-SOURCES = ["core.cpp", "hessian.hip", "cholesky.hip", "fasterquant.hip", "pack.hip", "matvec.hip"]
+SOURCES = ["core.cpp", "hessian.hip", "cholesky.hip", "fasterquant.hip", "quant_super.hip", "pack.hip", "matvec.hip"]
 # -ffp-contract=off: the quantize / error-feedback chain must round exactly like the reference's
 # separate torch ops (no implicit FMA); MFMA and explicit fmaf() are unaffected.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
 # The factorization chain is tolerance-level by construction (its reductions already differ from
 # LAPACK's order), so FMA contraction is allowed there.
-PER_FILE_FLAGS = {"cholesky.hip": ["-ffp-contract=fast"]}
+PER_FILE_FLAGS = {"cholesky.hip": ["-ffp-contract=fast"],
+                  # the SLP vectorizer pairs scalar fp32 operations of different columns into v_pk_* (slower beside a
+                  # dependent chain, MI355X_MICROARCH.md) and ties their live ranges together: hundreds of spills
+                  "quant_super.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:

@@ -630,6 +630,23 @@ extern "C" int gptq_quant_block(float* W, int ldw, int R, int C, int i1, int cou
   return launch_quant_block(a, blocksize, col_group != nullptr, static_cast<hipStream_t>(stream));
 }
 
+// quant_super.hip: the column loop of a whole super-block in one launch (factor form, static or no groups)
+namespace gptq {
+struct QuantSuperArgs {
+  float* W; int ldw; int R; int s0; int nb;
+  const float* U; int ldu;
+  const float* scale_tab; const float* zero_tab; int tab_ld; const int32_t* col_group;
+  float maxq;
+  float* Err; int lde;
+  uint8_t* codes; int ldc; const int32_t* col_map;
+  float* loss;
+  const float* w0; int ldw0;
+  int codes_wide;
+};
+}
+int quant_super_lanes(int R);
+int launch_quant_super(const gptq::QuantSuperArgs& a, bool grouped, int lanes, hipStream_t s);
+
 namespace {
 // The column loop keeps gptq.py's lazy-batch blocks (blocksize columns: quantize, compensate inside the block) but applies
 // their trailing updates on two levels: after every block only to the rest of its SUPER-block of SUPER * blocksize
@@ -784,10 +801,22 @@ extern "C" int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R
   // column loop needs them next) and "everything beyond" (helper stream, underneath the next super-block's loop).
   bool side_busy = false;
   int sblk = 0;
+  // One launch per super-block (quant_super.hip) whenever the factor form runs with static or no groups and every row
+  // allows 16-byte accesses; the per-block launches below remain for everything else.
+  auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+  const int qs_lanes = (rform && hier && !(grouped && !use_static) && bvec_base && ldk % 4 == 0 && al16(Wk) && al16(ws.W0) &&
+                        al16(ws.Err)) ? quant_super_lanes(R) : 0;
   for (int s0 = 0; s0 < C; s0 += SB, ++sblk) {
     const int s1 = std::min(s0 + SB, C);
     float* ErrS = ws.Err + (size_t)(sblk & 1) * R * SUPER * blocksize;   // [R, SB]: block b of the super-block at column b * blocksize
-    for (int i1 = s0; i1 < s1; i1 += blocksize) {                    // gptq.py:191
+    if (qs_lanes) {
+      QuantSuperArgs qa{Wk, ldk, R, s0, (s1 - s0) / blocksize, H, ldh, ws.stab, ws.ztab, G, grouped ? ws.cgroup : nullptr, maxq,
+                        ErrS, SB, codes, C, perm, ws.loss, ws.W0, C,
+                        (codes && !perm && C % 16 == 0 && al16(codes)) ? 1 : 0};
+      const int rc = launch_quant_super(qa, grouped, qs_lanes, s);
+      if (rc != GPTQ_OK) return rc;
+    }
+    for (int i1 = s0; i1 < s1 && !qs_lanes; i1 += blocksize) {       // gptq.py:191
       const int i2 = std::min(i1 + blocksize, s1);
       const int count = i2 - i1;
       float* Err = ErrS + (i1 - s0);

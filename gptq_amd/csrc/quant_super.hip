@@ -1,0 +1,461 @@
+// Column loop of one SUPER-BLOCK (up to 4 lazy-batch blocks of 128 columns, gptq.py:191-276) in ONE launch.
+//
+// Why: the per-block kernel (fasterquant.hip, quant_block_kernel) gives a row to a quad of lanes, so a 4096-row Linear
+// occupies 256 of the chip's 1024 SIMDs with one wave each, and every block pays a launch, a 64 x 64-tile rank-128
+// update launch (latency-bound: ~25 us for ~0.1 us of MFMA work per CU) and two launch boundaries: ~95 us per 128
+// columns in situ (profiles/r02_solve_trace_down_proj.txt), of which the dependent quantize chain itself is ~15 us.
+// Rows of W are independent problems given U (gptq.py:262-276 has no cross-row term), so here
+//   * a row is spread over L = 16 or 8 lanes (lane c holds block columns L t + c): 4x / 2x the waves for the same
+//     rows, a quarter / half of the in-block rank-1 update work per lane; every lane of a row runs the same
+//     (bitwise identical) quantize chain for a super-step of L columns, whose current values are exchanged with
+//     ds_bpermute (one instruction per column, off the dependent chain);
+//   * a workgroup (256 threads = 16 or 32 rows) walks ALL blocks of the super-block: after a block it applies that
+//     block's rank-128 update to the rest of the super-block's columns of ITS rows itself, on the matrix cores
+//     (v_mfma_f32_16x16x4_f32: the rows are the M dimension, the B operand comes straight from L2 -- every wave owns
+//     its own output columns, nothing is shared through LDS), so there is no launch, no grid-wide dependency and no
+//     second pass over W per block.  Only the rank-512 updates beyond the super-block remain separate launches.
+// Arithmetic: the in-block loop is the reference's IEEE fp32 sequence, operation for operation (true division,
+// round-half-even, separate multiply and subtract: -ffp-contract=off), exactly as in quant_block_kernel; the rank-128
+// update sums k = 0 .. 127 in ascending order from zero and subtracts the sum from W, like gemm_tile64 (an fp32 MFMA
+// is an fmaf chain, whatever its shape) -- results are bit-identical to the per-block path, whatever L.
+// Factor form only (gptq_fasterquant_rows: C % 128 == 0, blocksize 128): Err receives Q1 - W0.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace gptq {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct QuantSuperArgs {
+  float* W; int ldw; int R; int s0; int nb;          // columns [s0, s0 + 128 nb) of W [R, ldw]
+  const float* U; int ldu;                           // what gptq_rfactor_upper left in H: U_kk inside the diagonal blocks, Rt above
+  const float* scale_tab; const float* zero_tab; int tab_ld; const int32_t* col_group;   // col_group: nullable
+  float maxq;
+  float* Err; int lde;                               // [R, lde]: Q1 - W0 of block b at columns [128 b, 128 b + 128)
+  uint8_t* codes; int ldc; const int32_t* col_map;   // codes nullable; col_map nullable (act-order: original column)
+  float* loss;
+  const float* w0; int ldw0;                         // the original (permuted, dead columns zeroed) weights
+  int codes_wide;                                    // codes rows allow 8-byte stores and there is no column map
+};
+
+#ifdef GPTQ_DIAG   // diagnostic library only: s_memtime stamps of workgroup 0, block 0 of the LAST launch (tools/qs_phases.py)
+__device__ unsigned long long qs_stamps[32];
+#define QS_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && b == 0) qs_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define QS_STAMP(i) do { } while (0)
+#endif
+
+template <int L>
+struct QS {
+  static constexpr int ROWS = 256 / L;               // rows per workgroup
+  static constexpr int NT = 128 / L;                 // block columns per lane
+  static constexpr int SPP = 32 / L;                 // super-steps (of L columns) per 32-column phase
+  static constexpr int MT = ROWS / 16;               // 16-row MFMA tiles
+  static constexpr int NCH = NT / 4;                 // float4 chunks of a lane's slice of a U row
+  static constexpr int TLD = 132;                    // row stride of the transpose / A-operand tile
+  static constexpr int UBUF = 32 * 132;              // floats per U-row buffer: 32 x 128 staged rows; the tile aliases buffer 1
+  static constexpr int UD = 32 * L;                  // floats per dense diagonal sub-block buffer (SPP blocks of L x L)
+  static constexpr int CLD = 144;                    // byte stride of the code tile
+  static constexpr size_t LDS_BYTES = sizeof(float) * (2 * UBUF + 2 * UD) + ROWS * CLD + 2 * 128 * sizeof(int);
+};
+
+template <int L>
+__device__ __forceinline__ float lane_bcast(float v, int base4, int k) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(base4 + 4 * k, __builtin_bit_cast(int, v)));
+}
+
+// quant.py:9 -- clamp(round(x / s) + z, 0, maxq)
+__device__ __forceinline__ float qs_affine_code(float x, float s, float z, float maxq) {
+  return fminf(fmaxf(rintf(x / s) + z, 0.f), maxq);
+}
+
+// U rows [32 ph, 32 ph + 32) of the diagonal block at (i1, i1): thread `tid` fetches 4 float4 pieces (coalesced rows).
+__device__ __forceinline__ void qs_stage_fetch(const float* __restrict__ U, int ldu, int i1, int ph, int tid, f32x4 (&v)[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int idx = tid + 256 * j, il = idx >> 5, k4 = (idx & 31) * 4;
+    v[j] = *reinterpret_cast<const f32x4*>(U + (long)(i1 + 32 * ph + il) * ldu + i1 + k4);
+  }
+}
+// ... and scatters them into the lane-major image Us[il][c][t] (element k = L t + c of row il; the float4 chunks of a
+// lane's slice are XOR-swizzled by the lane's upper bits so that the 16 lanes of a ds_read_b128 group hit 64 distinct
+// banks without padding) plus the dense copy Ud[ss][cc][c2] of the L x L diagonal sub-blocks (the chain reads those
+// with wave-uniform addresses).
+template <int L>
+__device__ __forceinline__ void qs_stage_store(float* Us, float* Ud, int ph, int tid, const f32x4 (&v)[4]) {
+  constexpr int NT = QS<L>::NT;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int idx = tid + 256 * j, il = idx >> 5, k4 = (idx & 31) * 4;
+    const int i = 32 * ph + il;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = k4 + e, c = k % L, t = k / L;
+      const float x = (k >= i) ? v[j][e] : 0.f;                          // upper triangular block
+      const int sw = (c * NT) >> 6;                                      // chunk swizzle of lane c
+      Us[il * 128 + c * NT + ((((t >> 2) ^ sw) << 2) | (t & 3))] = x;
+      if (k / L == i / L) Ud[(il / L) * L * L + (il % L) * L + c] = x;   // same super-step: diagonal sub-block
+    }
+  }
+}
+
+// One super-step: L consecutive columns 32 PH + L SS ... of the block.
+template <int L, bool GROUPED, int PH, int SS>
+__device__ __forceinline__ void qs_super_step(float (&w)[QS<L>::NT], float (&cd)[QS<L>::NT],
+                                              const float (&psc)[QS<L>::NT], const float (&pzr)[QS<L>::NT], float sc,
+                                              float zr, float maxq, const float* Usb, const float* Udb, int c, int base4,
+                                              int swz, float& loss) {
+  constexpr int NT = QS<L>::NT, SPP = QS<L>::SPP, NCH = QS<L>::NCH;
+  constexpr int t = PH * SPP + SS;
+  float cur[L], gs[L], gz[L], errs[L];
+#pragma unroll
+  for (int cc = 0; cc < L; ++cc) cur[cc] = lane_bcast<L>(w[t], base4, cc);
+  if (GROUPED) {
+#pragma unroll
+    for (int cc = 0; cc < L; ++cc) {
+      gs[cc] = lane_bcast<L>(psc[t], base4, cc);
+      gz[cc] = lane_bcast<L>(pzr[t], base4, cc);
+    }
+  }
+  // (a) the dependent chain of the L columns (identical in every lane of the row)
+#pragma unroll
+  for (int cc = 0; cc < L; ++cc) {
+    // (without this the scheduler hoists the U reads of all L columns to the top of the super-step: L * L live registers)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    const float* ud = Udb + SS * L * L + cc * L;               // U[i][L t + c2], c2 = 0 .. L - 1 (wave-uniform address)
+    float urow[L];
+#pragma unroll
+    for (int k = cc / 4; k < L / 4; ++k) {
+      const f32x4 u4 = *reinterpret_cast<const f32x4*>(ud + 4 * k);
+      urow[4 * k] = u4[0]; urow[4 * k + 1] = u4[1]; urow[4 * k + 2] = u4[2]; urow[4 * k + 3] = u4[3];
+    }
+    float gsc = sc, gzr = zr;
+    if (GROUPED) { gsc = gs[cc]; gzr = gz[cc]; }
+    const float x = cur[cc];
+    const float code = qs_affine_code(x, gsc, gzr, maxq);      // gptq.py:262-264
+    const float q = gsc * (code - gzr);
+    const float d = urow[cc];                                  // Hinv1[i, i]
+    const float err = (x - q) / d;                             // gptq.py:269
+    errs[cc] = err;
+    loss += err * err;                                         // (w - q)^2 / d^2, gptq.py:267 (tolerance-level)
+    if (c == cc) { w[t] = q; cd[t] = code; }
+    // (pins the two selects HERE: left to itself the DAG scheduler sinks all L of them to the end of the super-step and
+    //  spills every column's code and q on the way)
+    asm volatile("" : "+v"(w[t]), "+v"(cd[t]));
+#pragma unroll
+    for (int c2 = cc + 1; c2 < L; ++c2) cur[c2] -= err * urow[c2];   // gptq.py:270
+  }
+  // (b) the L rank-1 updates of this lane's later columns, per element in the reference's order
+  if (t + 1 < NT) {
+#pragma unroll
+    for (int cc = 0; cc < L; ++cc) {
+      const int il = SS * L + cc;
+      const float err = errs[cc];
+      if (cc % 4 == 0) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+      for (int k = (t + 1) / 4; k < NCH; ++k) {
+        const f32x4 u4 = *reinterpret_cast<const f32x4*>(Usb + il * 128 + c * NT + ((k ^ swz) << 2));
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (4 * k + e > t) w[4 * k + e] -= err * u4[e];
+      }
+      // (pins the updates next to their U reads: the reads are ordered by the memory clobber above, the arithmetic is not,
+      //  and sunk behind ALL the reads of the super-step it turns every read into a spill)
+#pragma unroll
+      for (int j = t + 1; j < NT; ++j) asm volatile("" : "+v"(w[j]));
+    }
+  }
+}
+
+template <int L, bool GROUPED, int PH>
+__device__ __forceinline__ void qs_phase(const QuantSuperArgs& a, int i1_next, bool have_next, float (&w)[QS<L>::NT],
+                                         float (&cd)[QS<L>::NT], const float (&psc)[QS<L>::NT],
+                                         const float (&pzr)[QS<L>::NT], float sc, float zr, float* Us, float* Ud, int i1,
+                                         int c, int base4, int swz, int tid, float& loss) {
+  constexpr int UBUF = QS<L>::UBUF, UD = QS<L>::UD, SPP = QS<L>::SPP;
+  // Launder the per-lane indices once per phase: otherwise every LDS / bpermute address of all four phases (hundreds of
+  // distinct base + constant values) is hoisted out of the block loop as loop-invariant and spilled (measured: 1000
+  // spilled registers); laundered, an address is formed next to its use and folded into the instruction's offset field.
+  asm volatile("" : "+v"(c), "+v"(base4), "+v"(swz), "+v"(tid));
+  float* Usb = Us + (PH & 1) * UBUF;
+  float* Udb = Ud + (PH & 1) * UD;
+  __syncthreads();                                             // this phase's rows are staged; the other buffer is dead
+  // the rows of the NEXT phase (of the next block after phase 3) travel under the chain
+  f32x4 nxt[4];
+  const bool fetch = PH < 3 || have_next;                      // (workgroup-uniform)
+  if (fetch) qs_stage_fetch(a.U, a.ldu, PH < 3 ? i1 : i1_next, (PH + 1) & 3, tid, nxt);
+#define QS_STEP(S) if constexpr (SPP > S) qs_super_step<L, GROUPED, PH, S>(w, cd, psc, pzr, sc, zr, a.maxq, Usb, Udb, c, base4, swz, loss)
+  QS_STEP(0); QS_STEP(1); QS_STEP(2); QS_STEP(3);
+#undef QS_STEP
+  if (fetch) qs_stage_store<L>(Us + ((PH + 1) & 1) * UBUF, Ud + ((PH + 1) & 1) * UD, (PH + 1) & 3, tid, nxt);
+}
+
+// W[rows of this workgroup, cols] -= X[rows, 0:128] * Rt[i1 : i1 + 128, cols]  for the columns [c_lo, c_lo + 128 NREM):
+// wave wv owns the 32 NREM columns from c_lo + 32 NREM wv as 2 NREM tiles of 16 whose columns are chosen so that what a
+// lane holds of a B row (and of a W row) is contiguous AND the 16 lanes of a k row read one contiguous run: tile j of a
+// 4-tile segment holds the columns 4 n + j (a float4 per lane, 256 B per k row), of a 2-tile segment 2 n + j (float2).
+// The B operand comes straight from L2 into registers (every wave owns its columns: nothing to share through LDS), a ring
+// of 8 (4 for 32-row workgroups) k-groups deep: measured with batches of 4 k-groups the update took 32 k cycles for 6 k cycles of MFMAs.
+template <int NREM>
+__device__ __forceinline__ void qs_row_load(const float* p, int n, float (&dst)[2 * NREM]) {   // p: row base + the wave's first column
+  if constexpr (NREM == 1) {
+    const float2 v = *reinterpret_cast<const float2*>(p + 2 * n);
+    dst[0] = v.x; dst[1] = v.y;
+  } else {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p + 4 * n);
+    dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+    if constexpr (NREM == 3) {
+      const float2 u = *reinterpret_cast<const float2*>(p + 64 + 2 * n);
+      dst[4] = u.x; dst[5] = u.y;
+    }
+  }
+}
+template <int NREM>
+__device__ __forceinline__ void qs_row_store(float* p, int n, const float (&v)[2 * NREM]) {
+  if constexpr (NREM == 1) {
+    *reinterpret_cast<float2*>(p + 2 * n) = make_float2(v[0], v[1]);
+  } else {
+    *reinterpret_cast<f32x4*>(p + 4 * n) = f32x4{v[0], v[1], v[2], v[3]};
+    if constexpr (NREM == 3) *reinterpret_cast<float2*>(p + 64 + 2 * n) = make_float2(v[4], v[5]);
+  }
+}
+
+template <int L, int NREM>
+struct QsNear {
+  static constexpr int MT = QS<L>::MT, TLD = QS<L>::TLD, T = 2 * NREM;
+  static constexpr int NB_RING = MT == 1 ? 8 : 4;               // (32 rows per workgroup: twice the accumulators, half the ring)
+  static constexpr bool OLD_FIRST = false;                      // old values after the product (before it: 24-48 more live registers, spills)
+  float bq[NB_RING][T];
+  const float* Bp;
+  // the first NB_RING k-groups of B: issued before the block is retired (B does not depend on the block's results)
+  __device__ __forceinline__ void prefetch(const QuantSuperArgs& a, int i1, int c_lo, int tid) {
+    const int lane = tid & 63, wv = tid >> 6;
+    Bp = a.U + (long)(i1 + (lane >> 4)) * a.ldu + c_lo + 32 * NREM * wv;
+#pragma unroll
+    for (int u = 0; u < NB_RING; ++u) qs_row_load<NREM>(Bp + (long)(4 * u) * a.ldu, lane & 15, bq[u]);
+  }
+  __device__ __forceinline__ void run(const QuantSuperArgs& a, const float* Et, int c_lo, int row0, int tid) {
+    const int lane = tid & 63, wv = tid >> 6;
+    const int n = lane & 15, kq = lane >> 4;
+    const long wcol = (long)c_lo + 32 * NREM * wv;
+    float old[MT][4][T];
+    auto load_old = [&]() {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          qs_row_load<NREM>(a.W + (long)min(row0 + 16 * mt + 4 * kq + i, a.R - 1) * a.ldw + wcol, n, old[mt][i]);
+    };
+    if (OLD_FIRST) load_old();
+    f32x4 acc[MT][T];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int j = 0; j < T; ++j) acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* Ap = Et + n * TLD + kq;                        // A(m, k) = Et[m][k]
+#pragma unroll
+    for (int kg = 0; kg < 32; ++kg) {
+      float av[MT], bv[T];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) av[mt] = Ap[16 * mt * TLD + 4 * kg];
+#pragma unroll
+      for (int j = 0; j < T; ++j) bv[j] = bq[kg % NB_RING][j];
+      if (kg + NB_RING < 32) qs_row_load<NREM>(Bp + (long)(4 * (kg + NB_RING)) * a.ldu, n, bq[kg % NB_RING]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < T; ++j)
+          acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[j], acc[mt][j], 0, 0, 0);
+      // (keeps the ring's refill HERE: left alone the scheduler sinks every refill to just before its use, NB_RING
+      //  iterations later, and each k-group then pays a whole L2 round trip: measured 26 k cycles instead of 6 k)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!OLD_FIRST) load_old();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = row0 + 16 * mt + 4 * kq + i;
+        float out[T];
+#pragma unroll
+        for (int j = 0; j < T; ++j) out[j] = old[mt][i][j] - acc[mt][j][i];
+        if (r < a.R) qs_row_store<NREM>(a.W + (long)r * a.ldw + wcol, n, out);
+      }
+  }
+};
+
+// Retire block b (Q1 -> W, Q1 - W0 -> Err and -> the A-operand tile, codes) and apply its rank-128 update to the NREM
+// blocks that follow it in the super-block.
+template <int L, int NREM>
+__device__ __forceinline__ void qs_retire(const QuantSuperArgs& a, const float (&w)[QS<L>::NT], const float (&cd)[QS<L>::NT],
+                                          const f32x4 (&w0p)[QS<L>::NT / 4], float* T0, uint8_t* T1b, const int* cmap, int i1,
+                                          int b, int c, int row_l, int row0, long rbase, bool active, int tid) {
+  constexpr int NT = QS<L>::NT, TLD = QS<L>::TLD, CLD = QS<L>::CLD;
+    // ---- retire the block: Q1 -> W, Q1 - W0 -> Err (global, for the far updates) and -> the A-operand tile ----
+    QsNear<L, NREM == 0 ? 1 : NREM> near;
+    if constexpr (NREM > 0) near.prefetch(a, i1, i1 + 128, tid);
+    __syncthreads();                                           // every wave is done with phase 3's U rows (buffer 1)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      T0[row_l * TLD + L * t + c] = w[t];
+      T1b[row_l * CLD + L * t + c] = (uint8_t)cd[t];
+    }
+    if (a.codes && !a.codes_wide && active) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) a.codes[rbase * a.ldc + cmap[L * t + c]] = (uint8_t)cd[t];
+    }
+    __syncthreads();
+    {
+      float* tq = T0 + row_l * TLD + c * NT;
+#pragma unroll
+      for (int k = 0; k < NT / 4; ++k) {
+        const f32x4 q4 = *reinterpret_cast<const f32x4*>(tq + 4 * k);
+        const f32x4 x4 = q4 - w0p[k];                          // factor form: Q1 - W0
+        if (active) {
+          *reinterpret_cast<f32x4*>(a.W + rbase * a.ldw + i1 + c * NT + 4 * k) = q4;
+          *reinterpret_cast<f32x4*>(a.Err + rbase * a.lde + 128 * b + c * NT + 4 * k) = x4;
+        }
+        *reinterpret_cast<f32x4*>(tq + 4 * k) = x4;            // (read and written by this lane only)
+      }
+      if (a.codes && a.codes_wide && active) {
+        const uint8_t* tc = T1b + row_l * CLD + c * NT;
+        uint8_t* dst = a.codes + rbase * a.ldc + i1 + c * NT;
+        if (NT == 8) *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(tc);
+        else *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(tc);
+      }
+    }
+    QS_STAMP(6);
+    if constexpr (NREM > 0) {
+      __syncthreads();                                         // the A-operand tile is complete
+      near.run(a, T0, i1 + 128, row0, tid);
+    }
+}
+
+template <int L, bool GROUPED, int OCC>
+__global__ __launch_bounds__(256, OCC) void quant_super_kernel(QuantSuperArgs a) {
+  critical_path_priority();
+  constexpr int ROWS = QS<L>::ROWS, NT = QS<L>::NT, TLD = QS<L>::TLD, UBUF = QS<L>::UBUF, UD = QS<L>::UD, CLD = QS<L>::CLD;
+  extern __shared__ __attribute__((aligned(16))) float qs_lds[];
+  float* Us = qs_lds;                                          // [2][UBUF]
+  float* Ud = Us + 2 * UBUF;                                   // [2][UD]
+  uint8_t* T1b = reinterpret_cast<uint8_t*>(Ud + 2 * UD);      // [ROWS][CLD]
+  int* grp = reinterpret_cast<int*>(T1b + ROWS * CLD);         // [128]
+  int* cmap = grp + 128;                                       // [128]
+  float* T0 = Us + UBUF;                                       // [ROWS][TLD] over U buffer 1 (dead between phase 3 and the next phase 0's end)
+
+  const int tid0 = threadIdx.x;
+  const int c0 = tid0 % L, row_l0 = tid0 / L;
+  const int row0 = blockIdx.x * ROWS;
+  const int row = row0 + row_l0;
+  const bool active = row < a.R;
+  const long rbase = active ? row : a.R - 1;
+  const int base4 = ((tid0 & 63) & ~(L - 1)) << 2;
+  const int swz = (c0 * NT) >> 6;
+
+  float sc = 1.f, zr = 0.f;
+  if (!GROUPED) {
+    sc = a.scale_tab[rbase * a.tab_ld];
+    zr = a.zero_tab[rbase * a.tab_ld];
+  }
+  float loss_row = a.loss[rbase];
+
+  {                                                            // U rows of block 0, phase 0
+    f32x4 first[4];
+    qs_stage_fetch(a.U, a.ldu, a.s0, 0, tid0, first);
+    qs_stage_store<L>(Us, Ud, 0, tid0, first);
+  }
+#pragma unroll 1
+  for (int b = 0; b < a.nb; ++b) {
+    const int i1 = a.s0 + 128 * b;
+    int tid = tid0, c = c0, row_l = row_l0;
+    asm volatile("" : "+v"(tid), "+v"(c), "+v"(row_l));            // (see qs_phase: keeps address arithmetic inside the loop)
+    QS_STAMP(0);
+    if (tid < 128) {
+      grp[tid] = a.col_group ? a.col_group[i1 + tid] : 0;
+      cmap[tid] = a.col_map ? a.col_map[i1 + tid] : i1 + tid;
+    }
+    __syncthreads();                                           // grp / cmap; the previous block's updates of W are visible
+    float w[NT], cd[NT], psc[NT], pzr[NT];
+    const float* wrow = a.W + rbase * a.ldw + i1;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) w[t] = wrow[L * t + c];
+    if (GROUPED) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int g = grp[L * t + c];
+        psc[t] = a.scale_tab[rbase * a.tab_ld + g];
+        pzr[t] = a.zero_tab[rbase * a.tab_ld + g];
+      }
+    }
+    // the original weights of the columns this lane retires (c NT ... c NT + NT - 1 of the block)
+    f32x4 w0p[NT / 4];
+#pragma unroll
+    for (int k = 0; k < NT / 4; ++k)
+      w0p[k] = *reinterpret_cast<const f32x4*>(a.w0 + rbase * a.ldw0 + i1 + c * NT + 4 * k);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) cd[t] = 0.f;
+    float loss = 0.f;
+    const bool have_next = b + 1 < a.nb;
+    QS_STAMP(1);
+    qs_phase<L, GROUPED, 0>(a, i1 + 128, have_next, w, cd, psc, pzr, sc, zr, Us, Ud, i1, c, base4, swz, tid, loss);
+    QS_STAMP(2);
+    qs_phase<L, GROUPED, 1>(a, i1 + 128, have_next, w, cd, psc, pzr, sc, zr, Us, Ud, i1, c, base4, swz, tid, loss);
+    QS_STAMP(3);
+    qs_phase<L, GROUPED, 2>(a, i1 + 128, have_next, w, cd, psc, pzr, sc, zr, Us, Ud, i1, c, base4, swz, tid, loss);
+    QS_STAMP(4);
+    qs_phase<L, GROUPED, 3>(a, i1 + 128, have_next, w, cd, psc, pzr, sc, zr, Us, Ud, i1, c, base4, swz, tid, loss);
+    QS_STAMP(5);
+    loss_row += 0.5f * loss;                                   // gptq.py:274
+
+    {
+      const int nrem = a.nb - 1 - b;                           // (workgroup-uniform)
+      if (nrem == 3) qs_retire<L, 3>(a, w, cd, w0p, T0, T1b, cmap, i1, b, c, row_l, row0, rbase, active, tid);
+      else if (nrem == 2) qs_retire<L, 2>(a, w, cd, w0p, T0, T1b, cmap, i1, b, c, row_l, row0, rbase, active, tid);
+      else if (nrem == 1) qs_retire<L, 1>(a, w, cd, w0p, T0, T1b, cmap, i1, b, c, row_l, row0, rbase, active, tid);
+      else qs_retire<L, 0>(a, w, cd, w0p, T0, T1b, cmap, i1, b, c, row_l, row0, rbase, active, tid);
+    }
+    QS_STAMP(7);
+  }
+  if (active && c0 == 0) a.loss[row] = loss_row;
+}
+
+}  // namespace gptq
+
+using namespace gptq;
+
+#ifdef GPTQ_DIAG
+extern "C" int gptq_diag_qs_stamps(unsigned long long* out8) {
+  GPTQ_CHECK_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(qs_stamps), sizeof(unsigned long long) * 8));
+  return GPTQ_OK;
+}
+#endif
+
+// 0: the per-block path; 8 / 16: lanes per row of quant_super_kernel.  Default by rows: 16 lanes up to 8192 rows (one or
+// two waves per SIMD), 8 beyond (more rows per workgroup, three workgroups per compute unit).  GPTQ_QS_LANES overrides.
+int quant_super_lanes(int R) {
+  const char* e = getenv("GPTQ_QS_LANES");                 // (read per call: tests switch paths inside one process)
+  const int env = e ? atoi(e) : -1;
+  if (env == 0 || env == 8 || env == 16) return env;
+  return R <= 8192 ? 16 : 0;     // (8 lanes: correct, but the kernel still spills registers; the per-block path is faster beyond 8192 rows)
+}
+
+// Launch for one super-block.  Preconditions (checked by the caller, gptq_fasterquant_rows): factor form, 16-byte
+// aligned rows of W / W0 / Err / U, static or no groups.
+int launch_quant_super(const QuantSuperArgs& a, bool grouped, int lanes, hipStream_t s) {
+#define QS_LAUNCH(LL, GG, OCC)                                                                                     \
+  do {                                                                                                             \
+    GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&quant_super_kernel<LL, GG, OCC>),           \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)QS<LL>::LDS_BYTES));     \
+    quant_super_kernel<LL, GG, OCC><<<cdiv(a.R, QS<LL>::ROWS), 256, QS<LL>::LDS_BYTES, s>>>(a);                   \
+  } while (0)
+  if (lanes == 16) {
+    if (grouped) QS_LAUNCH(16, true, 2); else QS_LAUNCH(16, false, 2);
+  } else {
+    if (grouped) QS_LAUNCH(8, true, 2); else QS_LAUNCH(8, false, 2);
+  }
+#undef QS_LAUNCH
+  GPTQ_CHECK_LAUNCH("quant_super_kernel");
+  return GPTQ_OK;
+}

@@ -259,6 +259,32 @@ def test_factor_form_matches_inverse_form_of_the_solve():
             assert rows <= 2 and abs(ea - eb) <= 1e-3 * abs(eb), l
 
 
+@pytest.mark.parametrize("R,C,kw", [(70, 384, dict()), (1000, 640, dict(actorder=True)), (512, 1408, dict()),
+                                    (96, 1024, dict(groupsize=64, static_groups=True, actorder=True)),
+                                    (200, 512, dict(groupsize=128, static_groups=True)), (48, 256, dict(bits=3))])
+def test_super_block_kernel_bit_identical_to_per_block_path(G, R, C, kw, monkeypatch):
+    """quant_super.hip (one launch per super-block, 8 or 16 lanes per row, in-workgroup MFMA updates) against the
+    per-block launches (GPTQ_QS_LANES=0) on the same inputs: same arithmetic in the same order, so everything a caller
+    can see must be bit-identical -- codes, dequantized weights, grids, the error scalar."""
+    kw = dict(kw)
+    bits = kw.pop("bits", 4)
+    gen = torch.Generator().manual_seed(R * 7 + C)
+    W = (torch.randn(R, C, generator=gen) * 0.02).half().float()
+    X = torch.randn(2 * C, C, generator=gen) * (1 + torch.arange(C) % 7)
+    H = (X.t() @ X) * (2.0 / X.shape[0])
+    H[5, :] = 0; H[:, 5] = 0                            # a dead column (gptq.py:143-145)
+    out = {}
+    for lanes in ("0", "8", "16"):
+        monkeypatch.setenv("GPTQ_QS_LANES", lanes)
+        lin, gp = _run_gptq(G, W, H, 2, bits=bits, sym=False, blocksize=128, percdamp=0.01, **kw)
+        assert gp.Hinv_form == "rfactor"
+        out[lanes] = (gp.codes.cpu(), lin.weight.data.cpu(), gp.quantizer.scale.cpu(), gp.quantizer.zero.cpu(), gp.error)
+    for lanes in ("8", "16"):
+        for a, b in zip(out["0"][:4], out[lanes][:4]):
+            assert torch.equal(a, b), (lanes, int((a != b).sum()))
+        assert out["0"][4] == out[lanes][4], (lanes, out["0"][4], out[lanes][4])
+
+
 def test_hinv_not_positive_definite_raises(G, hip_device):
     C = 256
     H = -torch.eye(C)
