@@ -79,6 +79,13 @@ WORKLOADS = {
     "llama65b": dict(groups=_llama(8192, 22016), bits=4, groupsize=-1, actorder=True, static_groups=False,
                      desc="Llama-65B decoder block (BASELINE configs[4]): q,k,v,o 8192x8192, gate,up 22016x8192, down "
                           "8192x22016; 4-bit asym per-channel, act-order, true-sequential groups"),
+    # configs[4] as BASELINE words it ("per-block Linear layers sharded", no --true-sequential): ONE hooked group with four
+    # distinct Hessians (q/k/v share one, gate/up share one) whose chains run on disjoint rank sets (parallel.plan_rows)
+    "llama65b-1group": dict(groups=[[l for g in _llama(8192, 22016) for l in g]], bits=4, groupsize=-1, actorder=False,
+                            static_groups=False,
+                            desc="Llama-65B decoder block, all seven Linears hooked in one pass (BASELINE configs[4] as worded, "
+                                 "llama.py:97-105 without --true-sequential): q,k,v,o 8192x8192, gate,up 22016x8192, down "
+                                 "8192x22016; 4-bit asym per-channel"),
 }
 
 
@@ -106,6 +113,13 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary measurement on the other headline config")
     ap.add_argument("--also-steps", type=int, default=2)
+    ap.add_argument("--project-gpus", type=int, default=0, metavar="N",
+                    help="N = 1 only: add `projection` for N GPUs from measured single-GPU pieces (per distinct Hessian: the "
+                         "solve at full and at half the rows -> replicated chain + per-row cost; parallel.plan_rows)")
+    ap.add_argument("--end-to-end", type=int, default=-1, metavar="BLOCKS",
+                    help="add `end_to_end`: gptq_amd.sequential.quantize_sequential on a random-init Llama-7B-architecture "
+                         "model of BLOCKS decoder blocks (the reference's 'full quantization time' scope, opt.py:686-691); "
+                         "default: 2 blocks when the workload is llama7b on one GPU, 0 = off")
     ap.add_argument("--ppl-proxy", action="store_true",
                     help="add `ppl_proxy`: our OPT driver + evaluator vs the reference's numbers on the random-init OPT-125m "
                          "architecture of tests/golden/g6_opt125m.npz (a proxy: no Wiki2 / checkpoints offline)")
@@ -333,6 +347,8 @@ def main():
         solve_ms = (blk.phase_ms["solve"] + blk.phase_ms["pack"]) / steps
         out["phases"] = {k: round(v / steps, 3) for k, v in blk.phase_ms.items()}
         out["phases"]["solve_only_mparams_per_s"] = round(blk.params / (solve_ms / 1e3) / 1e6, 1) if solve_ms > 0 else None
+        if world == 1 and args.project_gpus > 1:
+            out["projection"] = projection(blk, args.project_gpus, blk.phase_ms["hessian"] / steps, dev)
     del blk
     torch.cuda.empty_cache()
     if world == 1:
@@ -363,6 +379,23 @@ def main():
         if cpu is not None:
             out["gpu_over_cpu"] = {"whole_path": round(out["value"] / cpu["value"], 1),
                                    "solve_only": round(out["phases"]["solve_only_mparams_per_s"] / cpu["solve_only_mparams_per_s"], 1)}
+    if rank == 0 and world == 1 and not args.no_also:
+        # the library's SAFE defaults (what a drop-in caller gets without opting in): add_batch launches its update before it
+        # returns (HESSIAN_DEFER = 1) and every Linear folds its inputs as the hooks fire (no lazy Hessians)
+        gmod.HESSIAN_DEFER, gmod.LAZY_HESSIANS = 1, False
+        b3 = Block(args.workload, args, dev, 0, 1)
+        el = b3.run(1, args.also_steps, barrier)
+        out["default_mode"] = {"hessian_defer": 1, "lazy_hessians": False, "steps": args.also_steps,
+                               "ms_per_step": round(el / args.also_steps * 1e3, 3),
+                               "value": round(b3.params / (el / args.also_steps) / 1e6, 2), "unit": "Mparams/s",
+                               "phases": {k: round(v / args.also_steps, 3) for k, v in b3.phase_ms.items()}}
+        del b3
+        torch.cuda.empty_cache()
+        gmod.HESSIAN_DEFER, gmod.LAZY_HESSIANS = args.hessian_defer, not args.no_lazy_hessians
+    e2e_blocks = args.end_to_end if args.end_to_end >= 0 else (2 if (world == 1 and args.workload == "llama7b") else 0)
+    if rank == 0 and world == 1 and e2e_blocks > 0:
+        gmod.HESSIAN_DEFER = 1
+        out["end_to_end"] = end_to_end(dev, e2e_blocks, args.nsamples, args.hessian_defer)
     if rank == 0 and world == 1 and args.ppl_proxy:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from test_gpu_driver import run_ppl_proxy
@@ -378,6 +411,125 @@ def main():
             real_stdout.write(json.dumps(out) + "\n")
     if dist_on:
         dist.destroy_process_group()
+
+
+def projection(blk, n_gpus, hessian_ms, dev):
+    """What `gptq_amd.parallel.fasterquant_sharded` would take on n_gpus, from pieces MEASURED on this one GPU (no 8-GPU
+    node was available to the builder; the driver's SCALE run is the real number).  Per hooked group and distinct
+    Hessian (bundle): the solve of its stacked rows at R and at R / 2 rows gives T(R) = chain + rows * R; the chain (it
+    depends on H only) is replicated on the bundle's ranks, the rows are split (plan_rows).  Hessians: samples are
+    sharded, so hessian_ms / n; exchange: ring all-reduce of the upper trapezoids and direct all-gather of packed rows
+    over xGMI at 300 GB/s effective per GPU (7 links x 153 GB/s nominal, MI355X guide)."""
+    import gptq_amd
+    from gptq_amd import parallel as par
+    G, wl = gptq_amd, blk.wl
+    kw = dict(blocksize=128, percdamp=0.01, groupsize=wl["groupsize"], actorder=wl["actorder"], static_groups=wl["static_groups"])
+    total, detail, exch = hessian_ms / n_gpus, [], 0.0
+    for g in blk.groups:
+        bundles = {}
+        for (n, r, c, key) in g:
+            bundles.setdefault((key, c), []).append((n, r))
+        shapes, fits = [], []
+        for (key, c), members in bundles.items():
+            R = sum(r for _, r in members)
+            gen = torch.Generator(device=dev).manual_seed(7)
+            X = torch.randn(2048, c, device=dev, generator=gen, dtype=torch.float16) * (1 + torch.arange(c, device=dev) % 7).half()
+            t = {}
+            for rows in (R, max(128, R // 2 // 128 * 128)):
+                best = 1e9
+                for _ in range(2):
+                    m = torch.nn.Linear(c, rows, bias=False, device=dev, dtype=torch.float16)
+                    m.weight.data = (torch.randn(rows, c, device=dev, generator=gen) * 0.02).half()
+                    s = G.GPTQ(m)
+                    s.quantizer = G.Quantizer(); s.quantizer.configure(wl["bits"], perchannel=True, sym=False, mse=False)
+                    s.add_batch(X.unsqueeze(0), None); s.add_batch(X.flip(0).unsqueeze(0), None)
+                    G.gptq.flush_pending()
+                    torch.cuda.synchronize(); t0 = time.perf_counter()
+                    s.fasterquant(**kw)
+                    torch.cuda.synchronize(); best = min(best, (time.perf_counter() - t0) * 1e3)
+                    s.free(); del m, s
+                t[rows] = best
+            (R1, T1), (R2, T2) = sorted(t.items(), reverse=True)
+            per_row = max(0.0, (T1 - T2) / (R1 - R2))
+            fits.append((max(0.0, T1 - per_row * R1), per_row))
+            shapes.append((c, R))
+            del X
+        plan = par.plan_rows(shapes, n_gpus)
+        load = [0.0] * n_gpus
+        for (chain, per_row), slabs in zip(fits, plan):
+            for (rk, a, e) in slabs:
+                load[rk] += chain + per_row * (e - a)
+        trap = sum(par.tri_numel(c) * 4 for c, _ in shapes)
+        packed = sum(c * R * wl["bits"] // 8 for c, R in shapes)
+        ex = (2 * (n_gpus - 1) / n_gpus * trap + (n_gpus - 1) / n_gpus * packed) / 300e9 * 1e3 if n_gpus > 1 else 0.0
+        total += max(load) + ex
+        exch += ex
+        detail.append({"bundles": [{"C": c, "rows": R, "chain_ms": round(f[0], 2), "ms_per_1k_rows": round(f[1] * 1e3, 3),
+                                    "ranks": len(sl)} for (c, R), f, sl in zip(shapes, fits, plan)],
+                       "solve_ms": round(max(load), 2), "exchange_ms": round(ex, 2)})
+    return {"n_gpus": n_gpus, "ms_per_step": round(total, 2), "mparams_per_s": round(blk.params / total / 1e3, 1),
+            "hessian_ms": round(hessian_ms / n_gpus, 2), "exchange_ms": round(exch, 2), "groups": detail,
+            "basis": "measured on 1 GPU: per distinct Hessian the solve at R and R/2 rows (chain replicated, rows split by "
+                     "parallel.plan_rows), Hessian time / n (samples sharded), exchanges at 300 GB/s per GPU; NOT a hardware number"}
+
+
+def end_to_end(dev, blocks, nsamples, hessian_defer):
+    """SURVEY 8(d) second scope, the reference's own `full quantization time` (opt.py:686-691, llama.py:31-207): capture of
+    the first block's inputs + per block {hooked calibration forwards of every true-sequential group, fasterquant, the
+    forward with quantized weights, block upload / download}.  Llama-7B architecture (hidden 4096, ffn 11008, 32 heads,
+    vocab 32000) with `blocks` decoder blocks, random init (no checkpoints offline), 128 x 2048 synthetic tokens, 4-bit,
+    --act-order --true-sequential.  Run twice: blocks moved synchronously like the reference, and prefetched."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from gptq_amd.sequential import QuantArgs, quantize_sequential
+    cfg = LlamaConfig(vocab_size=32000, hidden_size=4096, intermediate_size=11008, num_hidden_layers=blocks,
+                      num_attention_heads=32, num_key_value_heads=32, max_position_embeddings=SEQLEN)
+    t0 = time.perf_counter()
+    # random init without the CPU's normal_() over a billion parameters (20 s for two blocks): meta construction, weights
+    # drawn on the GPU (N(0, 0.02) like HF's initializer_range; norms = 1), rotary buffers rebuilt on the host
+    with torch.device("meta"):
+        model = LlamaForCausalLM(cfg).half()
+    model = model.to_empty(device="cpu").eval()
+    gen = torch.Generator(device=dev).manual_seed(0)
+    for _, p in model.named_parameters():
+        if p.dim() >= 2:
+            p.data.copy_(torch.randn(p.shape, device=dev, dtype=torch.float16, generator=gen) * 0.02)
+        else:
+            p.data.fill_(1.0)
+    model.model.rotary_emb = type(model.model.rotary_emb)(config=cfg)
+    model.seqlen = SEQLEN
+    log(f"end-to-end: {blocks}-block Llama-7B-architecture model built in {time.perf_counter() - t0:.1f} s")
+    saved = {k: v.clone() for k, v in model.state_dict().items()}
+    gen = torch.Generator().manual_seed(1)
+    calib = [(torch.randint(0, cfg.vocab_size, (1, SEQLEN), generator=gen), None) for _ in range(nsamples)]
+    params = sum(p.numel() for layer in model.model.layers for n, p in layer.named_parameters() if p.dim() == 2)
+    out = {"model": f"Llama-7B architecture, {blocks} decoder blocks ({params / 1e6:.0f} M Linear params), random init, "
+                    f"{nsamples} x {SEQLEN} synthetic tokens, 4-bit --act-order --true-sequential",
+           "scope": "capture + per block: 4 hooked calibration passes (one per true-sequential group) + fasterquant + "
+                    "forward with quantized weights + block transfer (opt.py:686-691)"}
+    for prefetch in (False, True):
+        model.load_state_dict(saved)
+        tm = {}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        # first run: the reference's behaviour (blocks moved on the compute stream, full hooked passes); second: this
+        # driver's defaults (copy-stream prefetch / download, hooked passes left once the group's hooks have fired)
+        quantize_sequential(model, calib, dev, QuantArgs(wbits=4, nsamples=nsamples, act_order=True, true_sequential=True,
+                                                         hessian_defer=hessian_defer, prefetch_blocks=prefetch,
+                                                         early_exit=prefetch), timings=tm)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        per = lambda k: round(tm.get(k, 0.0) / blocks, 2)
+        out["driver_defaults" if prefetch else "reference_like"] = {
+            "prefetch_blocks": prefetch, "early_exit_of_hooked_passes": prefetch,
+            "wall_s": round(wall, 3), "s_per_block": round(wall / blocks, 3),
+            "mparams_per_s": round(params / wall / 1e6, 2),
+            "gpu_ms_per_block": {"forward_hooked_incl_hessian": per("forward_hooked"), "hessian": per("hessian"),
+                                 "forwards_alone": round(per("forward_hooked") - per("hessian") + per("forward_final"), 2),
+                                 "solve": per("solve"), "forward_final": per("forward_final"), "transfer_waited": per("transfer")}}
+        log(f"end-to-end ({'driver defaults' if prefetch else 'reference-like'}): {wall:.2f} s for {blocks} blocks")
+    del model, saved
+    torch.cuda.empty_cache()
+    return out
 
 
 def cpu_baseline(name, wl, nsamples):

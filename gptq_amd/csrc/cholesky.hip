@@ -394,8 +394,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void syrk128_kernel(float* __restrict
   const long r0 = (long)tm * NB, c0 = (long)tn * NB;
   Operand<float> a{A + r0 * Cp + k0, Cp, 1, NB, true};
   Operand<float> b{A + c0 * Cp + k0, Cp, 1, NB, true};
-  gemm_tile<float, float, true, true>(a, b, 0, K, smem,
-                                      Epilogue{A + r0 * Cp + c0, Cp, 1, EPI_SUB, tm == tn ? TRI_LOWER : TRI_ALL, 0.f, 0.f});
+  gemm_tile<float, float, true, true, true>(a, b, 0, K, smem,
+                                            Epilogue{A + r0 * Cp + c0, Cp, 1, EPI_SUB, tm == tn ? TRI_LOWER : TRI_ALL, 0.f, 0.f});
 }
 static inline int syrk_tiles(int nblk, int tn0, int tn1) {       // sum_{tn in [tn0, tn1)} (nblk - tn)
   const int n = tn1 - tn0;

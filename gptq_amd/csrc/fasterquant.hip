@@ -495,7 +495,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void trailing128_kernel(float* __rest
   Operand<float> a{E + r0 * lde, lde, 1, (int)min((long)GBM, R - r0),
                    (lde % 4) == 0 && reinterpret_cast<uintptr_t>(E) % 16 == 0};
   Operand<float> b{U + (long)u0 * ldu + c0, 1, ldu, (int)min((long)GBN, c_end - c0), bvec};
-  gemm_tile<float, float, true, false>(a, b, 0, K, smem, Epilogue{W + r0 * ldw + c0, ldw, 1, EPI_SUB, TRI_ALL, 0.f, 0.f});
+  gemm_tile<float, float, true, false, true>(a, b, 0, K, smem, Epilogue{W + r0 * ldw + c0, ldw, 1, EPI_SUB, TRI_ALL, 0.f, 0.f});
 }
 
 // ---------------------------------------------------------------------------------------------

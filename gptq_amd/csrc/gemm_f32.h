@@ -148,23 +148,26 @@ struct Epilogue {
   float alpha, beta;   // EPI_AXPBY: C = alpha * C + beta * acc
 };
 
-__device__ __forceinline__ void tile_epilogue(const f32x16 (&acc)[2][2], const Epilogue& ep, int rem_m,
-                                              int rem_n, int wm, int wn, int lane) {
-  // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+// The old values of a read-modify-write epilogue, loaded BEFORE the product (the tile belongs to this workgroup alone):
+// after the k loop the 64 loads were a whole L2 round trip at the end of every tile (gemm2_f32.h measured the same on
+// the 64 x 64 tile).
+__device__ __forceinline__ void tile_load_old(float (&old)[2][2][16], const Epilogue& ep, int rem_m, int rem_n, int wm,
+                                              int wn, int lane) {
   const bool rmw = ep.mode == EPI_SUB || ep.mode == EPI_AXPBY;
-  float old[2][2][16];
-  if (rmw) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-          const int col = wn * 64 + j * 32 + (lane & 31);
-          old[i][j][e] = (row < rem_m && col < rem_n) ? ep.C[(long)row * ep.rs + (long)col * ep.cs] : 0.f;
-        }
-  }
+      for (int e = 0; e < 16; ++e) {
+        const int row = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        const int col = wn * 64 + j * 32 + (lane & 31);
+        old[i][j][e] = (rmw && row < rem_m && col < rem_n) ? ep.C[(long)row * ep.rs + (long)col * ep.cs] : 0.f;
+      }
+}
+__device__ __forceinline__ void tile_finish(const f32x16 (&acc)[2][2], const float (&old)[2][2][16], const Epilogue& ep,
+                                            int rem_m, int rem_n, int wm, int wn, int lane) {
+  // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -185,10 +188,16 @@ __device__ __forceinline__ void tile_epilogue(const f32x16 (&acc)[2][2], const E
         if (keep) ep.C[(long)row * ep.rs + (long)col * ep.cs] = out;
       }
 }
+__device__ __forceinline__ void tile_epilogue(const f32x16 (&acc)[2][2], const Epilogue& ep, int rem_m,
+                                              int rem_n, int wm, int wn, int lane) {
+  float old[2][2][16];
+  tile_load_old(old, ep, rem_m, rem_n, wm, wn, lane);
+  tile_finish(acc, old, ep, rem_m, rem_n, wm, wn, lane);
+}
 
 // C_tile = sum_{k in [k_begin, k_end)} A(m,k) * B(n,k), combined with memory as `ep` says.
 // `smem` must hold GEMM_LDS_FLOATS floats.
-template <typename TA, typename TB, bool AKC, bool BKC>
+template <typename TA, typename TB, bool AKC, bool BKC, bool PRELOAD_OLD = false>
 __device__ __forceinline__ void gemm_tile(const Operand<TA>& a, const Operand<TB>& b, int k_begin,
                                           int k_end, float* smem, const Epilogue& ep) {
   const int tid = threadIdx.x;
@@ -208,6 +217,8 @@ __device__ __forceinline__ void gemm_tile(const Operand<TA>& a, const Operand<TB
 
   float ra[GST][4], rb[GST][4];
   const int nk = (k_end - k_begin + GBK - 1) / GBK;
+  float old[2][2][16];
+  if (PRELOAD_OLD) tile_load_old(old, ep, a.rem, b.rem, wm, wn, lane);   // in flight under the whole product
   if (nk > 0) {
     stage_load<TA, AKC>(a, k_begin, k_end, ra);
     stage_load<TB, BKC>(b, k_begin, k_end, rb);
@@ -242,7 +253,8 @@ __device__ __forceinline__ void gemm_tile(const Operand<TA>& a, const Operand<TB
     __syncthreads();
     cur ^= 1;
   }
-  tile_epilogue(acc, ep, a.rem, b.rem, wm, wn, lane);
+  if (PRELOAD_OLD) tile_finish(acc, old, ep, a.rem, b.rem, wm, wn, lane);
+  else tile_epilogue(acc, ep, a.rem, b.rem, wm, wn, lane);
 }
 
 template <typename T>

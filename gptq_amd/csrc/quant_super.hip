@@ -193,96 +193,84 @@ __device__ __forceinline__ void qs_phase(const QuantSuperArgs& a, int i1_next, b
 }
 
 // W[rows of this workgroup, cols] -= X[rows, 0:128] * Rt[i1 : i1 + 128, cols]  for the columns [c_lo, c_lo + 128 NREM):
-// wave wv owns the 32 NREM columns from c_lo + 32 NREM wv as 2 NREM tiles of 16 whose columns are chosen so that what a
-// lane holds of a B row (and of a W row) is contiguous AND the 16 lanes of a k row read one contiguous run: tile j of a
-// 4-tile segment holds the columns 4 n + j (a float4 per lane, 256 B per k row), of a 2-tile segment 2 n + j (float2).
+// wave wv owns the 32 NREM columns from c_lo + 32 NREM wv, processed as segments of TS = 4 or 2 MFMA tiles of 16 columns
+// (NREM = 1: one 2-tile segment, 2: one 4-tile segment, 3: a 4-tile and a 2-tile segment).  The columns of a segment's
+// tiles are chosen so that what a lane holds of a B row (and of a W row) is contiguous AND the 16 lanes of a k row read
+// one contiguous run: tile j holds the columns TS n + j (one float4 / float2 per lane and row).
 // The B operand comes straight from L2 into registers (every wave owns its columns: nothing to share through LDS), a ring
-// of 8 (4 for 32-row workgroups) k-groups deep: measured with batches of 4 k-groups the update took 32 k cycles for 6 k cycles of MFMAs.
-template <int NREM>
-__device__ __forceinline__ void qs_row_load(const float* p, int n, float (&dst)[2 * NREM]) {   // p: row base + the wave's first column
-  if constexpr (NREM == 1) {
+// of 8 (4 for 32-row workgroups) k-groups deep; its first loads are issued before the block is retired (B does not depend
+// on the block's results).  Measured on the way: batches of 4 k-groups 32 k cycles per update (6 k of MFMAs), a ring whose
+// refills the scheduler was free to sink 26 k, pinned refills 14 k.
+template <int TS>
+__device__ __forceinline__ void qs_seg_load(const float* p, int n, float (&dst)[TS]) {   // p: row base + the segment's first column
+  if constexpr (TS == 2) {
     const float2 v = *reinterpret_cast<const float2*>(p + 2 * n);
     dst[0] = v.x; dst[1] = v.y;
   } else {
     const f32x4 v = *reinterpret_cast<const f32x4*>(p + 4 * n);
     dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
-    if constexpr (NREM == 3) {
-      const float2 u = *reinterpret_cast<const float2*>(p + 64 + 2 * n);
-      dst[4] = u.x; dst[5] = u.y;
-    }
   }
 }
-template <int NREM>
-__device__ __forceinline__ void qs_row_store(float* p, int n, const float (&v)[2 * NREM]) {
-  if constexpr (NREM == 1) {
-    *reinterpret_cast<float2*>(p + 2 * n) = make_float2(v[0], v[1]);
-  } else {
-    *reinterpret_cast<f32x4*>(p + 4 * n) = f32x4{v[0], v[1], v[2], v[3]};
-    if constexpr (NREM == 3) *reinterpret_cast<float2*>(p + 64 + 2 * n) = make_float2(v[4], v[5]);
-  }
+template <int TS>
+__device__ __forceinline__ void qs_seg_store(float* p, int n, const float (&v)[TS]) {
+  if constexpr (TS == 2) *reinterpret_cast<float2*>(p + 2 * n) = make_float2(v[0], v[1]);
+  else *reinterpret_cast<f32x4*>(p + 4 * n) = f32x4{v[0], v[1], v[2], v[3]};
 }
 
-template <int L, int NREM>
+template <int L, int TS>
 struct QsNear {
-  static constexpr int MT = QS<L>::MT, TLD = QS<L>::TLD, T = 2 * NREM;
-  static constexpr int NB_RING = MT == 1 ? 8 : 4;               // (32 rows per workgroup: twice the accumulators, half the ring)
-  static constexpr bool OLD_FIRST = false;                      // old values after the product (before it: 24-48 more live registers, spills)
-  float bq[NB_RING][T];
+  static constexpr int MT = QS<L>::MT, TLD = QS<L>::TLD;
+  static constexpr int RING = MT == 1 ? 8 : 4;                  // (32 rows per workgroup: twice the accumulators, half the ring)
+  float bq[RING][TS];
   const float* Bp;
-  // the first NB_RING k-groups of B: issued before the block is retired (B does not depend on the block's results)
-  __device__ __forceinline__ void prefetch(const QuantSuperArgs& a, int i1, int c_lo, int tid) {
-    const int lane = tid & 63, wv = tid >> 6;
-    Bp = a.U + (long)(i1 + (lane >> 4)) * a.ldu + c_lo + 32 * NREM * wv;
+  __device__ __forceinline__ void prefetch(const QuantSuperArgs& a, int i1, long col, int tid) {   // col: the segment's first column
+    const int lane = tid & 63;
+    Bp = a.U + (long)(i1 + (lane >> 4)) * a.ldu + col;
 #pragma unroll
-    for (int u = 0; u < NB_RING; ++u) qs_row_load<NREM>(Bp + (long)(4 * u) * a.ldu, lane & 15, bq[u]);
+    for (int u = 0; u < RING; ++u) qs_seg_load<TS>(Bp + (long)(4 * u) * a.ldu, lane & 15, bq[u]);
   }
-  __device__ __forceinline__ void run(const QuantSuperArgs& a, const float* Et, int c_lo, int row0, int tid) {
-    const int lane = tid & 63, wv = tid >> 6;
+  __device__ __forceinline__ void run(const QuantSuperArgs& a, const float* Et, long col, int row0, int tid) {
+    const int lane = tid & 63;
     const int n = lane & 15, kq = lane >> 4;
-    const long wcol = (long)c_lo + 32 * NREM * wv;
-    float old[MT][4][T];
-    auto load_old = [&]() {
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          qs_row_load<NREM>(a.W + (long)min(row0 + 16 * mt + 4 * kq + i, a.R - 1) * a.ldw + wcol, n, old[mt][i]);
-    };
-    if (OLD_FIRST) load_old();
-    f32x4 acc[MT][T];
+    f32x4 acc[MT][TS];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int j = 0; j < T; ++j) acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < TS; ++j) acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* Ap = Et + n * TLD + kq;                        // A(m, k) = Et[m][k]
 #pragma unroll
     for (int kg = 0; kg < 32; ++kg) {
-      float av[MT], bv[T];
+      float av[MT], bv[TS];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) av[mt] = Ap[16 * mt * TLD + 4 * kg];
 #pragma unroll
-      for (int j = 0; j < T; ++j) bv[j] = bq[kg % NB_RING][j];
-      if (kg + NB_RING < 32) qs_row_load<NREM>(Bp + (long)(4 * (kg + NB_RING)) * a.ldu, n, bq[kg % NB_RING]);
+      for (int j = 0; j < TS; ++j) bv[j] = bq[kg % RING][j];
+      if (kg + RING < 32) qs_seg_load<TS>(Bp + (long)(4 * (kg + RING)) * a.ldu, n, bq[kg % RING]);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int j = 0; j < T; ++j)
+        for (int j = 0; j < TS; ++j)
           acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[j], acc[mt][j], 0, 0, 0);
-      // (keeps the ring's refill HERE: left alone the scheduler sinks every refill to just before its use, NB_RING
-      //  iterations later, and each k-group then pays a whole L2 round trip: measured 26 k cycles instead of 6 k)
+      // (keeps the ring's refill HERE: left alone the scheduler sinks every refill to just before its use, RING
+      //  iterations later, and each k-group then pays a whole L2 round trip)
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (!OLD_FIRST) load_old();
+    // old values after the product (before it: MT * 4 * TS more live registers)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt) {
+      float old[4][TS];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        qs_seg_load<TS>(a.W + (long)min(row0 + 16 * mt + 4 * kq + i, a.R - 1) * a.ldw + col, n, old[i]);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int r = row0 + 16 * mt + 4 * kq + i;
-        float out[T];
+        float out[TS];
 #pragma unroll
-        for (int j = 0; j < T; ++j) out[j] = old[mt][i][j] - acc[mt][j][i];
-        if (r < a.R) qs_row_store<NREM>(a.W + (long)r * a.ldw + wcol, n, out);
+        for (int j = 0; j < TS; ++j) out[j] = old[i][j] - acc[mt][j][i];
+        if (r < a.R) qs_seg_store<TS>(a.W + (long)r * a.ldw + col, n, out);
       }
+    }
   }
 };
 
@@ -290,12 +278,21 @@ struct QsNear {
 // blocks that follow it in the super-block.
 template <int L, int NREM>
 __device__ __forceinline__ void qs_retire(const QuantSuperArgs& a, const float (&w)[QS<L>::NT], const float (&cd)[QS<L>::NT],
-                                          const f32x4 (&w0p)[QS<L>::NT / 4], float* T0, uint8_t* T1b, const int* cmap, int i1,
+                                          float* T0, uint8_t* T1b, const int* cmap, int i1,
                                           int b, int c, int row_l, int row0, long rbase, bool active, int tid) {
   constexpr int NT = QS<L>::NT, TLD = QS<L>::TLD, CLD = QS<L>::CLD;
     // ---- retire the block: Q1 -> W, Q1 - W0 -> Err (global, for the far updates) and -> the A-operand tile ----
-    QsNear<L, NREM == 0 ? 1 : NREM> near;
-    if constexpr (NREM > 0) near.prefetch(a, i1, i1 + 128, tid);
+    // the wave's columns of the NREM blocks that follow: [wcol, wcol + 32 NREM)
+    const long wcol = (long)i1 + 128 + 32 * NREM * (tid >> 6);
+    QsNear<L, NREM == 1 ? 2 : 4> near;
+    QsNear<L, 2> near2;                                         // (NREM == 3: its last 32 columns)
+    if constexpr (NREM > 0) near.prefetch(a, i1, wcol, tid);
+    // the original weights of the columns this lane retires (c NT ... c NT + NT - 1 of the block): loaded HERE, under the
+    // transposes -- held across the four phases they were spilled to scratch at 168 registers (8 lanes per row)
+    f32x4 w0p[NT / 4];
+#pragma unroll
+    for (int k = 0; k < NT / 4; ++k)
+      w0p[k] = *reinterpret_cast<const f32x4*>(a.w0 + rbase * a.ldw0 + i1 + c * NT + 4 * k);
     __syncthreads();                                           // every wave is done with phase 3's U rows (buffer 1)
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -329,7 +326,9 @@ __device__ __forceinline__ void qs_retire(const QuantSuperArgs& a, const float (
     QS_STAMP(6);
     if constexpr (NREM > 0) {
       __syncthreads();                                         // the A-operand tile is complete
-      near.run(a, T0, i1 + 128, row0, tid);
+      if constexpr (NREM == 3) near2.prefetch(a, i1, wcol + 64, tid);
+      near.run(a, T0, wcol, row0, tid);
+      if constexpr (NREM == 3) near2.run(a, T0, wcol + 64, row0, tid);
     }
 }
 
@@ -389,11 +388,6 @@ __global__ __launch_bounds__(256, OCC) void quant_super_kernel(QuantSuperArgs a)
         pzr[t] = a.zero_tab[rbase * a.tab_ld + g];
       }
     }
-    // the original weights of the columns this lane retires (c NT ... c NT + NT - 1 of the block)
-    f32x4 w0p[NT / 4];
-#pragma unroll
-    for (int k = 0; k < NT / 4; ++k)
-      w0p[k] = *reinterpret_cast<const f32x4*>(a.w0 + rbase * a.ldw0 + i1 + c * NT + 4 * k);
 #pragma unroll
     for (int t = 0; t < NT; ++t) cd[t] = 0.f;
     float loss = 0.f;
@@ -411,10 +405,10 @@ __global__ __launch_bounds__(256, OCC) void quant_super_kernel(QuantSuperArgs a)
 
     {
       const int nrem = a.nb - 1 - b;                           // (workgroup-uniform)
-      if (nrem == 3) qs_retire<L, 3>(a, w, cd, w0p, T0, T1b, cmap, i1, b, c, row_l, row0, rbase, active, tid);
-      else if (nrem == 2) qs_retire<L, 2>(a, w, cd, w0p, T0, T1b, cmap, i1, b, c, row_l, row0, rbase, active, tid);
-      else if (nrem == 1) qs_retire<L, 1>(a, w, cd, w0p, T0, T1b, cmap, i1, b, c, row_l, row0, rbase, active, tid);
-      else qs_retire<L, 0>(a, w, cd, w0p, T0, T1b, cmap, i1, b, c, row_l, row0, rbase, active, tid);
+      if (nrem == 3) qs_retire<L, 3>(a, w, cd, T0, T1b, cmap, i1, b, c, row_l, row0, rbase, active, tid);
+      else if (nrem == 2) qs_retire<L, 2>(a, w, cd, T0, T1b, cmap, i1, b, c, row_l, row0, rbase, active, tid);
+      else if (nrem == 1) qs_retire<L, 1>(a, w, cd, T0, T1b, cmap, i1, b, c, row_l, row0, rbase, active, tid);
+      else qs_retire<L, 0>(a, w, cd, T0, T1b, cmap, i1, b, c, row_l, row0, rbase, active, tid);
     }
     QS_STAMP(7);
   }
@@ -438,7 +432,9 @@ int quant_super_lanes(int R) {
   const char* e = getenv("GPTQ_QS_LANES");                 // (read per call: tests switch paths inside one process)
   const int env = e ? atoi(e) : -1;
   if (env == 0 || env == 8 || env == 16) return env;
-  return R <= 8192 ? 16 : 0;     // (8 lanes: correct, but the kernel still spills registers; the per-block path is faster beyond 8192 rows)
+  // measured (solve of R x 4096, act-order): 4096 rows 4.23 -> 3.78 ms, 12288 6.42 -> 6.00 (8 lanes), 16384 7.37 -> 7.06, 22016
+  // 8.62 -> 8.84: beyond 16384 rows the 8-lane kernel needs two rounds of workgroups (256 registers: two per compute unit)
+  return R <= 8192 ? 16 : R <= 16384 ? 8 : 0;
 }
 
 // Launch for one super-block.  Preconditions (checked by the caller, gptq_fasterquant_rows): factor form, 16-byte

@@ -209,14 +209,16 @@ def fasterquant_sharded(solvers, bits: int, group=None, blocksize: int = 128, pe
     order = sorted(mine, key=lambda t: -(C_of[t[0]] ** 3 + (t[2] - t[1]) * C_of[t[0]] ** 2))
     for k, (bi, a, e) in enumerate(order):
         b = bundles[bi]
-        W = _stacked_rows(b, a, e)
         L = b[0]
         H = L._H
         st = lanes[k % want]
         if st is not cur:
             H.record_stream(st)
-            W.record_stream(st)
         with torch.cuda.stream(st):
+            # the slab is gathered ON the lane that solves it: gathered on the caller's stream after the lanes' wait_stream
+            # above, a side lane could start its solve before the copy had run (seen as a wrong `error` of one bundle
+            # once nothing else synchronised the device between blocks)
+            W = _stacked_rows(b, a, e)
             states[(bi, a, e)] = gmod._enqueue_rows(dev, W, H, L.quantizer, None, blocksize, percdamp, groupsize,
                                                     actorder, static_groups)
     for st in lanes[1:]:

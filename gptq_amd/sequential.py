@@ -45,6 +45,9 @@ class QuantArgs:
     nearest: bool = False
     blocksize: int = 128
     hessian_defer: int = 16     # hook inputs folded into H per launch (gptq_amd.gptq.HESSIAN_DEFER)
+    prefetch_blocks: bool = __import__('os').environ.get('GPTQ_SEQ_PREFETCH', '1') == '1'   # upload block i + 1 / download block i - 1 on a copy stream while block i is calibrated and
+                                   # solved (the reference moves blocks synchronously, opt.py:104, 219)
+    early_exit: bool = __import__('os').environ.get('GPTQ_SEQ_EARLY', '1') == '1'        # leave a hooked calibration pass once every Linear of the group has fired its hook
 
 
 class _Stop(Exception):
@@ -113,7 +116,7 @@ def _run_layer(layer, x, kwargs):
 
 
 @torch.no_grad()
-def quantize_sequential(model, dataloader, dev, args: QuantArgs, group=None) -> Dict[str, Quantizer]:
+def quantize_sequential(model, dataloader, dev, args: QuantArgs, group=None, timings: Optional[dict] = None) -> Dict[str, Quantizer]:
     """GPTQ every Linear of every decoder block; returns {full_name: quantizer} like the reference.
 
     With torch.distributed initialised (one process per GPU) the run is DATA-PARALLEL over the calibration samples
@@ -132,13 +135,95 @@ def quantize_sequential(model, dataloader, dev, args: QuantArgs, group=None) -> 
     # deferral is safe here: every hooked forward produces fresh activation tensors and nothing below writes into them
     _gptq_mod.HESSIAN_DEFER = max(1, int(args.hessian_defer))
     try:
-        return _quantize_sequential(model, dataloader, dev, args, group, world, rank)
+        return _quantize_sequential(model, dataloader, dev, args, group, world, rank, timings)
     finally:
         _gptq_mod.HESSIAN_DEFER = old_defer            # later drop-in use in this process gets the safe default back
 
 
-def _quantize_sequential(model, dataloader, dev, args, group, world, rank):
+class _BlockMover:
+    """Block i on the device while it is worked on, block i + 1 already on its way and block i - 1 on its way back, both
+    on a copy stream through page-locked host buffers.  The reference does `layers[i].to(dev)` ... `layers[i].cpu()` on
+    the compute stream (opt.py:104, 219); `prefetch=False` does exactly that."""
+
+    def __init__(self, layers, dev, prefetch):
+        self.layers, self.dev, self.prefetch = layers, dev, prefetch
+        self.stream = torch.cuda.Stream(device=dev) if prefetch else None
+        self.ready = {}          # block index -> event recorded on the copy stream after its upload
+        self.host = {}           # block index -> [(tensor holder, page-locked host tensor)] for the way back
+        self.pending = []        # (event, block index): downloads in flight
+
+    def _tensors(self, i):
+        return list(self.layers[i].parameters()) + list(self.layers[i].buffers())
+
+    def _upload(self, i):
+        if i >= len(self.layers) or i in self.ready:
+            return
+        with torch.cuda.stream(self.stream):
+            pairs = []
+            for p in self._tensors(i):
+                if p.device.type != "cpu":
+                    continue
+                h = p.data if p.data.is_pinned() else p.data.pin_memory()   # page-locked: the copies really are asynchronous
+                pairs.append((p, h))
+                p.data = h.to(self.dev, non_blocking=True)
+            self.host[i] = pairs
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self.ready[i] = ev
+
+    def fetch(self, i):
+        """Block i on the device (the compute stream waits for its upload); starts the upload of block i + 1."""
+        if not self.prefetch:
+            self.layers[i] = self.layers[i].to(self.dev)
+            return self.layers[i]
+        self._upload(i)
+        cur = torch.cuda.current_stream(self.dev)
+        cur.wait_event(self.ready.pop(i))
+        for t in self._tensors(i):
+            t.data.record_stream(cur)                # allocated on the copy stream, used (and freed) on this one
+        return self.layers[i]
+
+    def prefetch_next(self, i):
+        """Start the upload of block i + 1 (call it once work for block i is enqueued: page-locking the next block's
+        weights is host work that would otherwise leave the GPU idle)."""
+        if self.prefetch:
+            self._upload(i + 1)
+
+    def release(self, i):
+        if not self.prefetch:
+            self.layers[i] = self.layers[i].cpu()
+            torch.cuda.empty_cache()
+            return
+        # download behind the block's last use, on the copy stream, into the page-locked buffers it came from: the host
+        # does not wait, and there is no empty_cache() (a device-wide synchronisation per block)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(done)
+            for p, h in self.host.pop(i, []):
+                d = p.data
+                h.copy_(d, non_blocking=True)
+                d.record_stream(self.stream)
+                p.data = h
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self.pending.append(ev)
+
+    def finish(self):
+        for ev in self.pending:
+            ev.synchronize()                         # every block is back on the host
+        self.pending = []
+
+
+class _GroupDone(Exception):
+    pass
+
+
+def _quantize_sequential(model, dataloader, dev, args, group, world, rank, timings=None):
+    import time
+    from . import gptq as gmod
     from . import parallel as par
+    t_wall = time.perf_counter()
     use_cache = model.config.use_cache
     model.config.use_cache = False
     fam = _family(model)
@@ -152,8 +237,27 @@ def _quantize_sequential(model, dataloader, dev, args, group, world, rank):
     records: List[dict] = []
     kw = dict(blocksize=args.blocksize, percdamp=args.percdamp, groupsize=args.groupsize, actorder=args.act_order,
               static_groups=static_groups)
+    mover = _BlockMover(layers, dev, bool(args.prefetch_blocks))
+    marks = []                                                  # (phase, start event, end event)
+    flush_events = [] if timings is not None else None
+
+    def timed(phase):
+        class _T:
+            def __enter__(self_):
+                if timings is not None:
+                    self_.a = torch.cuda.Event(enable_timing=True)
+                    self_.a.record()
+
+            def __exit__(self_, *exc):
+                if timings is not None:
+                    b = torch.cuda.Event(enable_timing=True)
+                    b.record()
+                    marks.append((phase, self_.a, b))
+        return _T()
+
     for i in range(len(layers)):
-        layer = layers[i].to(dev)
+        with timed("transfer"):
+            layer = mover.fetch(i)
         full = find_layers(layer)
         if args.true_sequential and fam["kind"] == "llama":
             groups = [[n for n in g if n in full] for g in LLAMA_GROUPS]
@@ -169,33 +273,59 @@ def _quantize_sequential(model, dataloader, dev, args, group, world, rank):
                 solvers[n].quantizer = Quantizer()
                 solvers[n].quantizer.configure(args.wbits, perchannel=True, sym=args.sym, mse=False)
 
+            # A hooked pass only exists to feed add_batch (its outputs are overwritten by the pass with quantized weights
+            # below, opt.py:216-217): once every Linear of the group has seen the sample, the rest of the block forward
+            # is skipped.  Same hook inputs as the reference's full passes; [k,v,q] stops in front of the attention.
+            seen = set()
+
             def hook(name):
                 def fn(_, inp, out):
                     solvers[name].add_batch(inp[0].data, out.data)
+                    seen.add(name)
+                    if args.early_exit and len(seen) == len(names):
+                        raise _GroupDone
                 return fn
 
             handles = [full[n].register_forward_hook(hook(n)) for n in names]
-            for j in range(len(mine)):
-                outs[j] = _run_layer(layer, inps[j], kwargs)
+            gmod.FLUSH_EVENTS = flush_events
+            with timed("forward_hooked"):
+                for j in range(len(mine)):
+                    seen.clear()
+                    try:
+                        outs[j] = _run_layer(layer, inps[j], kwargs)
+                    except _GroupDone:
+                        pass
             for h in handles:
                 h.remove()
-            if world > 1:
-                par.fasterquant_sharded([solvers[n] for n in names], bits=args.wbits, group=group, **kw)
-            else:
-                fasterquant_many([solvers[n] for n in names], **kw)
+            mover.prefetch_next(i)
+            with timed("solve"):
+                if world > 1:
+                    par.fasterquant_sharded([solvers[n] for n in names], bits=args.wbits, group=group, **kw)
+                else:
+                    fasterquant_many([solvers[n] for n in names], **kw)
+            gmod.FLUSH_EVENTS = None
             for n in names:
                 key = f"{fam['prefix']}.{i}.{n}"
                 quantizers[key] = solvers[n].quantizer
                 records.append(dict(name=key, error=solvers[n].error))
                 solvers[n].free()
-        for j in range(len(mine)):                            # opt.py:216-217: next block sees quantized outputs
-            outs[j] = _run_layer(layer, inps[j], kwargs)
-        layers[i] = layer.cpu()
+        with timed("forward_final"):
+            for j in range(len(mine)):                        # opt.py:216-217: next block sees quantized outputs
+                outs[j] = _run_layer(layer, inps[j], kwargs)
         del layer
-        torch.cuda.empty_cache()
+        with timed("transfer"):
+            mover.release(i)
         inps, outs = outs, inps
+    mover.finish()
     model.config.use_cache = use_cache
     quantize_sequential.last_records = records
+    if timings is not None:
+        torch.cuda.synchronize(dev)
+        for phase, a, b in marks:
+            timings[phase] = timings.get(phase, 0.0) + a.elapsed_time(b)
+        timings["hessian"] = timings.get("hessian", 0.0) + sum(a.elapsed_time(b) for (_, _, a, b) in flush_events)
+        timings["blocks"] = len(layers)
+        timings["wall_s"] = time.perf_counter() - t_wall
     return quantizers
 
 
