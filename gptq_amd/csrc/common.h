@@ -5,6 +5,7 @@
 #include <hip/hip_bf16.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/gptq_hip.h"
 
@@ -56,6 +57,14 @@ int lookahead_mask();               // bit 0: factorization chain, bit 1: column
 // stream's far-update GEMMs that share their SIMDs (s_setprio: 0 = default ... 3).
 #if defined(__HIPCC__)
 __device__ __forceinline__ void critical_path_priority() { __builtin_amdgcn_s_setprio(3); }
+#endif
+
+// Tuning knobs that were measured and settled (each is documented where it is used) are compile-time constants in the
+// product library; only the diagnostic library (-DGPTQ_DIAG) still reads them from the environment, for re-measuring.
+#ifdef GPTQ_DIAG
+static inline int tune_knob(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#else
+static inline int tune_knob(const char*, int dflt) { return dflt; }
 #endif
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -23,7 +23,7 @@ SideCtx* side_ctx(hipStream_t main) {
   if (it != table.end()) return &it->second;
   // HIP maps streams onto few hardware queues (4 by default) and streams sharing one serialize: by default only
   // the first caller stream per device gets a helper (GPTQ_SIDE_STREAMS raises that); the others run serially.
-  static const int limit = [] { const char* e = getenv("GPTQ_SIDE_STREAMS"); return e ? atoi(e) : 1; }();
+  static const int limit = tune_knob("GPTQ_SIDE_STREAMS", 1);
   int mine = 0;
   for (const auto& kv : table) mine += kv.first.first == dev;
   if (mine >= limit) return nullptr;

@@ -562,7 +562,7 @@ extern "C" int gptq_quantize_rows(float* X, int ldx, int R, int C, const float* 
 
 // QuantBlockArgs::wide for a launch (a full block whose rows allow 16-byte accesses; see quant_phase's retire)
 static int quant_block_wide(const QuantBlockArgs& a, int blocksize) {
-  static const int off = [] { const char* e = getenv("GPTQ_QB_WIDE"); return e && atoi(e) == 0; }();
+  static const int off = tune_knob("GPTQ_QB_WIDE", 1) == 0;
   auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
   // (128 or 256 columns: the transpose tiles need the U-row buffer of at least four phases; full blocks only)
   if (off || (blocksize != 128 && blocksize != 256) || a.count != blocksize || a.errw != blocksize) return 0;
@@ -593,7 +593,7 @@ static int launch_quant_block(const QuantBlockArgs& a, int blocksize, bool group
     if (grouped) quant_block_kernel<NPH, true><<<grid, 256, 0, s>>>(a);               \
     else quant_block_kernel<NPH, false><<<grid, 256, 0, s>>>(a);                      \
     break;
-  static const int occ_env = [] { const char* e = getenv("GPTQ_QB_OCC"); return e ? atoi(e) : 0; }();
+  static const int occ_env = tune_knob("GPTQ_QB_OCC", 0);
   if (blocksize > 64 && blocksize <= 128 && (occ_env == 2 || (occ_env == 0 && grid > 256))) {
     if (grouped) quant_block_kernel<4, true, 0, 2><<<grid, 256, 0, s>>>(a);
     else quant_block_kernel<4, false, 0, 2><<<grid, 256, 0, s>>>(a);

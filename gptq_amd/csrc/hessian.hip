@@ -1082,7 +1082,7 @@ static int hessian_launch_big(const HostProb* probs, int n_prob, int n_x, int x_
         plan.workers = cdiv((long)left * nk_all, plan.chunk);
         size_t slots = 2 * (size_t)plan.workers;
         // heads + tails (16x16x32 kernel; see BigPlan): while a tail run touches at most BIG_MAXSEG tiles
-        static const int heads_env = [] { const char* e = getenv("GPTQ_HESS_HEADS"); return e ? atoi(e) : 1; }();
+        static const int heads_env = tune_knob("GPTQ_HESS_HEADS", 1);
         const int tail_len = nk_all - plan.chunk;
         // (measured: the split round of C = 11008, 178 tiles, 0.83 -> 0.60 ms and 5.6 -> 3.0 GB; but 4-7 % SLOWER at
         //  136 tiles (C = 4096) and 16 tiles (C = 8192), where equal runs happen to line up and more segments cost more
@@ -1103,11 +1103,11 @@ static int hessian_launch_big(const HostProb* probs, int n_prob, int n_x, int x_
       // single launch the later rounds start one by one as compute units free up; a tile that starts 5 % of a tile
       // time after its neighbours is 50 stages behind them, far outside what 4 MB of L2 keeps.
       // (A launch sized for a CU budget keeps the single strided launch.)
-      static const int rounds_env = [] { const char* e = getenv("GPTQ_HESS_ROUNDS"); return e ? atoi(e) : 1; }();
+      static const int rounds_env = tune_knob("GPTQ_HESS_ROUNDS", 1);
       const int items = plan.dp_tiles + plan.workers;
       const bool by_rounds = rounds_env != 0 && cu_limit <= 0;
       const int per_launch = by_rounds ? n_cu : items;
-      static const int bring_env = [] { const char* e = getenv("GPTQ_HESS_RING"); return e ? atoi(e) : BRING_DEFAULT; }();
+      static const int bring_env = tune_knob("GPTQ_HESS_RING", BRING_DEFAULT);
 #ifdef GPTQ_DIAG   // timing-only ablation builds exist in the diagnostic library alone (python -m gptq_amd.build --diag)
       static const int babl_env = [] { const char* e = getenv("GPTQ_HESS_ABLATE"); return e ? atoi(e) : 0; }();
 #endif
@@ -1172,7 +1172,7 @@ static int hessian_launch(const HostProb* probs, int n_prob, int n_x, int x_dtyp
     if (big_ok && (big_env >= 2 || big_tiles >= 100))
       return hessian_launch_big(probs, n_prob, n_x, x_dtype, tokens, cu_limit, s);
     if (aligned) {
-      static const int ring_env = [] { const char* e = getenv("GPTQ_HESS_RING"); return e ? atoi(e) : RING_DEFAULT; }();
+      static const int ring_env = tune_knob("GPTQ_HESS_RING", RING_DEFAULT);
       const size_t lds = (size_t)ring_env * DSTAGE;
 #ifdef GPTQ_DIAG
       static const int ablate = [] { const char* e = getenv("GPTQ_HESS_ABLATE"); return e ? atoi(e) : 0; }();

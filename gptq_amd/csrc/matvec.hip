@@ -373,7 +373,7 @@ static int launch_matvec(const void* vec, int vec_dtype, const int32_t* mat, flo
     // on the FC2 shape, kernel time from rocprofv3 -- 8: 28.4 us, 16: 30.3, 32-80 with a 4-deep refill ring: 33-35
     // (3-bit, fp32 x).  What bounds it is vector issue, not HBM: window + and_or + 2 fma_mix = 4 + 4 + 8 + 8 cycles
     // per two weights and SIMD, 340 M weights -> 29 us; nontemporal loads were slower (34 us) on this MALL-resident shape.
-    static const int kg2_env = [] { const char* e = getenv("GPTQ_MV_KGROUPS"); return e ? atoi(e) : 0; }();
+    static const int kg2_env = tune_knob("GPTQ_MV_KGROUPS", 0);
     const int colblocks = cdiv(width, 256);
     int kg = kg2_env > 0 ? std::min(kg2_env, MV2_KG_MAX) : 8;
     kg = std::max(1, std::min(kg, ngroups));
@@ -405,7 +405,7 @@ static int launch_matvec(const void* vec, int vec_dtype, const int32_t* mat, flo
     GPTQ_CHECK_LAUNCH(who);
     return GPTQ_OK;
   }
-  static const int kg_env = [] { const char* e = getenv("GPTQ_MV_KGROUPS"); return e ? atoi(e) : 0; }();
+  static const int kg_env = tune_knob("GPTQ_MV_KGROUPS", 0);
   int kgroups = kg_env > 0 ? std::min(kg_env, MV_KGROUPS_MAX) : 16;   // measured best on the 36864 x 9216 FC2 shape
   const dim3 grid(cdiv(width, 64 * vw), cdiv(ngroups, kgroups));
   GPTQ_CHECK_ARG(grid.y <= 65535, "%s: too many input groups", who);
@@ -418,8 +418,9 @@ static int launch_matvec(const void* vec, int vec_dtype, const int32_t* mat, flo
       matvec_kernel<BITS, VW, TV, false><<<grid, 256, 0, s>>>(static_cast<const TV*>(vec), mat, mul, scales,       \
                                                               zeros, ngroups, width, kgroups, groupsize);          \
   } while (0)
-  if (vec_dtype == GPTQ_F32) { if (v4) MV_LAUNCH(4, float); else MV_LAUNCH(1, float); }
-  else { if (v4) MV_LAUNCH(4, __half); else MV_LAUNCH(1, __half); }
+  // (only the scalar-width instantiation of the first-generation kernel remains: widths that are no multiple of 4, or
+  //  an unaligned buffer; everything else took the kernel above)
+  if (vec_dtype == GPTQ_F32) MV_LAUNCH(1, float); else MV_LAUNCH(1, __half);
 #undef MV_LAUNCH
   GPTQ_CHECK_LAUNCH(who);
   return GPTQ_OK;
