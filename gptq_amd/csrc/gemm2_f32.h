@@ -151,11 +151,20 @@ __device__ __forceinline__ void gemm_acc64(const Operand<TA>& a, const Operand<T
     constexpr int LDA = LdsStride64<AKC>::v, LDB = LdsStride64<BKC>::v;
     const float* Ac = As + cur * GBK * 68 + wm * 32 + (lane & 31);
     const float* Bc = Bs + cur * GBK * 68 + wn * 32 + (lane & 31);
+    // all fragments of the stage first, then the MFMA chain: read one k-pair at a time straight in front of its MFMA (as
+    // hipcc keeps such a loop) every 64-cycle MFMA waited for a ~100-cycle LDS round trip -- the k loop of a rank-128
+    // update took 8.3 k cycles for 4.1 k cycles of MFMAs (round-2 stamps)
+    float fa[GBK / 2], fb[GBK / 2];
 #pragma unroll
     for (int kk = 0; kk < GBK; kk += 2) {
       const int k = kk + (lane >> 5);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[k * LDA], Bc[k * LDB], acc, 0, 0, 0);
+      fa[kk / 2] = Ac[k * LDA];
+      fb[kk / 2] = Bc[k * LDB];
     }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < GBK; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk / 2], fb[kk / 2], acc, 0, 0, 0);
     if (more) {
       stage_store64<AKC>(As + (cur ^ 1) * GBK * 68, ra);
       stage_store64<BKC>(Bs + (cur ^ 1) * GBK * 68, rb);
@@ -207,20 +216,29 @@ __device__ __forceinline__ void gemm_acc64x2(const Operand<TA>& a, const Operand
     const float* Ac = As + cur * GBK * 68 + wm * 32 + (lane & 31);
     const float* B0c = B0s + cur * GBK * 68 + wn * 32 + (lane & 31);
     const float* B1c = B1s + cur * GBK * 68 + wn * 32 + (lane & 31);
+    float fa[GBK / 2], fb1[GBK / 2];                                  // (fragments first, see gemm_acc64)
+#pragma unroll
+    for (int kk = 0; kk < GBK; kk += 2) {
+      const int k = kk + (lane >> 5);
+      fa[kk / 2] = Ac[k * LDA];
+      fb1[kk / 2] = B1c[k * LDB];
+    }
     if (kt < nk0) {
+      float fb0[GBK / 2];
+#pragma unroll
+      for (int kk = 0; kk < GBK; kk += 2) fb0[kk / 2] = B0c[(kk + (lane >> 5)) * LDB];
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int kk = 0; kk < GBK; kk += 2) {
-        const int k = kk + (lane >> 5);
-        const float av = Ac[k * LDA];
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, B0c[k * LDB], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, B1c[k * LDB], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk / 2], fb0[kk / 2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk / 2], fb1[kk / 2], acc1, 0, 0, 0);
       }
     } else {
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int kk = 0; kk < GBK; kk += 2) {
-        const int k = kk + (lane >> 5);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[k * LDA], B1c[k * LDB], acc1, 0, 0, 0);
-      }
+      for (int kk = 0; kk < GBK; kk += 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk / 2], fb1[kk / 2], acc1, 0, 0, 0);
     }
     if (more) {
       stage_store64<AKC>(As + (cur ^ 1) * GBK * 68, ra);

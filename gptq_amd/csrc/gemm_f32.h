@@ -236,15 +236,24 @@ __device__ __forceinline__ void gemm_tile(const Operand<TA>& a, const Operand<TB
     constexpr int LDA = LdsStride<AKC>::v, LDB = LdsStride<BKC>::v;
     const float* Ac = As + cur * GBK * GLD + wm * 64 + (lane & 31);
     const float* Bc = Bs + cur * GBK * GLD + wn * 64 + (lane & 31);
+    // Operand fragments one k-pair AHEAD of the matrix cores: read straight in front of their four MFMAs (as this loop
+    // was first written, and as hipcc kept it: ds_read, s_waitcnt lgkmcnt(0), 4 MFMAs) every k-pair exposed an LDS round
+    // trip behind 256 cycles of MFMA issue -- the rank-4096 microbenchmark stopped at 75 % of the fp32 matrix peak.
+    const int kq = lane >> 5;
+    float a0 = Ac[kq * LDA], a1 = Ac[kq * LDA + 32];
+    float b0 = Bc[kq * LDB], b1 = Bc[kq * LDB + 32];
 #pragma unroll
     for (int kk = 0; kk < GBK; kk += 2) {
-      const int k = kk + (lane >> 5);
-      const float a0 = Ac[k * LDA], a1 = Ac[k * LDA + 32];
-      const float b0 = Bc[k * LDB], b1 = Bc[k * LDB + 32];
+      const int kn = (kk + 2 < GBK ? kk + 2 : kk) + kq;            // (last pair: a harmless re-read)
+      const float na0 = Ac[kn * LDA], na1 = Ac[kn * LDA + 32];
+      const float nb0 = Bc[kn * LDB], nb1 = Bc[kn * LDB + 32];
+      asm volatile("" ::: "memory");                               // (or the reads sink back to just before their use)
+      __builtin_amdgcn_sched_barrier(0);
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
     }
     if (more) {
       stage_store<AKC>(As + (cur ^ 1) * GBK * GLD, ra);
