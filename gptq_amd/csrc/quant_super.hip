@@ -54,10 +54,13 @@ struct QS {
   static constexpr int MT = ROWS / 16;               // 16-row MFMA tiles
   static constexpr int NCH = NT / 4;                 // float4 chunks of a lane's slice of a U row
   static constexpr int TLD = 132;                    // row stride of the transpose / A-operand tile
-  static constexpr int UBUF = 32 * 132;              // floats per U-row buffer: 32 x 128 staged rows; the tile aliases buffer 1
+  static constexpr int UBUF = 32 * 128;              // floats per U-row buffer: 32 staged rows of the 128 x 128 diagonal block
   static constexpr int UD = 32 * L;                  // floats per dense diagonal sub-block buffer (SPP blocks of L x L)
   static constexpr int CLD = 144;                    // byte stride of the code tile
-  static constexpr size_t LDS_BYTES = sizeof(float) * (2 * UBUF + 2 * UD) + ROWS * CLD + 2 * 128 * sizeof(int);
+  // U-row buffers: two (the next phase's rows are stored while this phase still reads its own) for 16 lanes; ONE for 8
+  // lanes (a second barrier per phase instead of 17 KB: 40 KB per workgroup = three per compute unit also by LDS)
+  static constexpr int NBUF = L == 16 ? 2 : 1;
+  static constexpr size_t LDS_BYTES = sizeof(float) * (NBUF * UBUF + NBUF * UD + ROWS * TLD) + ROWS * CLD + 2 * 128 * sizeof(int);
 };
 
 template <int L>
@@ -171,25 +174,40 @@ __device__ __forceinline__ void qs_super_step(float (&w)[QS<L>::NT], float (&cd)
 
 template <int L, bool GROUPED, int PH>
 __device__ __forceinline__ void qs_phase(const QuantSuperArgs& a, int i1_next, bool have_next, float (&w)[QS<L>::NT],
-                                         float (&cd)[QS<L>::NT], const float (&psc)[QS<L>::NT],
-                                         const float (&pzr)[QS<L>::NT], float sc, float zr, float* Us, float* Ud, int i1,
-                                         int c, int base4, int swz, int tid, float& loss) {
-  constexpr int UBUF = QS<L>::UBUF, UD = QS<L>::UD, SPP = QS<L>::SPP;
+                                         const float (&psc)[QS<L>::NT], const float (&pzr)[QS<L>::NT], float sc, float zr,
+                                         float* Us, float* Ud, float* T0, uint8_t* T1b, const int* cmap, int i1, int c,
+                                         int row_l, long rbase, bool active, int base4, int swz, int tid, float& loss) {
+  constexpr int UBUF = QS<L>::UBUF, UD = QS<L>::UD, SPP = QS<L>::SPP, NBUF = QS<L>::NBUF, NT = QS<L>::NT;
+  constexpr int TLD = QS<L>::TLD, CLD = QS<L>::CLD;
   // Launder the per-lane indices once per phase: otherwise every LDS / bpermute address of all four phases (hundreds of
   // distinct base + constant values) is hoisted out of the block loop as loop-invariant and spilled (measured: 1000
   // spilled registers); laundered, an address is formed next to its use and folded into the instruction's offset field.
-  asm volatile("" : "+v"(c), "+v"(base4), "+v"(swz), "+v"(tid));
-  float* Usb = Us + (PH & 1) * UBUF;
-  float* Udb = Ud + (PH & 1) * UD;
-  __syncthreads();                                             // this phase's rows are staged; the other buffer is dead
+  asm volatile("" : "+v"(c), "+v"(base4), "+v"(swz), "+v"(tid), "+v"(row_l));
+  float* Usb = Us + (NBUF == 2 ? (PH & 1) * UBUF : 0);
+  float* Udb = Ud + (NBUF == 2 ? (PH & 1) * UD : 0);
+  __syncthreads();                                             // this phase's rows are staged (two buffers: the other one is dead)
   // the rows of the NEXT phase (of the next block after phase 3) travel under the chain
   f32x4 nxt[4];
   const bool fetch = PH < 3 || have_next;                      // (workgroup-uniform)
   if (fetch) qs_stage_fetch(a.U, a.ldu, PH < 3 ? i1 : i1_next, (PH + 1) & 3, tid, nxt);
+  float cd[NT];                                                // (only this phase's SPP entries are used)
 #define QS_STEP(S) if constexpr (SPP > S) qs_super_step<L, GROUPED, PH, S>(w, cd, psc, pzr, sc, zr, a.maxq, Usb, Udb, c, base4, swz, loss)
   QS_STEP(0); QS_STEP(1); QS_STEP(2); QS_STEP(3);
 #undef QS_STEP
-  if (fetch) qs_stage_store<L>(Us + ((PH + 1) & 1) * UBUF, Ud + ((PH + 1) & 1) * UD, (PH + 1) & 3, tid, nxt);
+  // This phase's columns are final: into the transpose tiles NOW (the block's retire reads them back row-contiguous).
+  // Kept in registers until the block's end they were spilled to scratch by the later phases and re-loaded one by one.
+#pragma unroll
+  for (int ss = 0; ss < SPP; ++ss) {
+    const int t = PH * SPP + ss;
+    T0[row_l * TLD + L * t + c] = w[t];
+    T1b[row_l * CLD + L * t + c] = (uint8_t)cd[t];
+    if (a.codes && !a.codes_wide && active) a.codes[rbase * a.ldc + cmap[L * t + c]] = (uint8_t)cd[t];
+  }
+  if (fetch) {
+    if (NBUF == 1) __syncthreads();                            // every wave is done reading the (single) buffer
+    qs_stage_store<L>(Us + (NBUF == 2 ? ((PH + 1) & 1) * UBUF : 0), Ud + (NBUF == 2 ? ((PH + 1) & 1) * UD : 0), (PH + 1) & 3,
+                      tid, nxt);
+  }
 }
 
 // W[rows of this workgroup, cols] -= X[rows, 0:128] * Rt[i1 : i1 + 128, cols]  for the columns [c_lo, c_lo + 128 NREM):
@@ -277,8 +295,7 @@ struct QsNear {
 // Retire block b (Q1 -> W, Q1 - W0 -> Err and -> the A-operand tile, codes) and apply its rank-128 update to the NREM
 // blocks that follow it in the super-block.
 template <int L, int NREM>
-__device__ __forceinline__ void qs_retire(const QuantSuperArgs& a, const float (&w)[QS<L>::NT], const float (&cd)[QS<L>::NT],
-                                          float* T0, uint8_t* T1b, const int* cmap, int i1,
+__device__ __forceinline__ void qs_retire(const QuantSuperArgs& a, float* T0, const uint8_t* T1b, int i1,
                                           int b, int c, int row_l, int row0, long rbase, bool active, int tid) {
   constexpr int NT = QS<L>::NT, TLD = QS<L>::TLD, CLD = QS<L>::CLD;
     // ---- retire the block: Q1 -> W, Q1 - W0 -> Err (global, for the far updates) and -> the A-operand tile ----
@@ -293,17 +310,7 @@ __device__ __forceinline__ void qs_retire(const QuantSuperArgs& a, const float (
 #pragma unroll
     for (int k = 0; k < NT / 4; ++k)
       w0p[k] = *reinterpret_cast<const f32x4*>(a.w0 + rbase * a.ldw0 + i1 + c * NT + 4 * k);
-    __syncthreads();                                           // every wave is done with phase 3's U rows (buffer 1)
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      T0[row_l * TLD + L * t + c] = w[t];
-      T1b[row_l * CLD + L * t + c] = (uint8_t)cd[t];
-    }
-    if (a.codes && !a.codes_wide && active) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t) a.codes[rbase * a.ldc + cmap[L * t + c]] = (uint8_t)cd[t];
-    }
-    __syncthreads();
+    __syncthreads();                                           // the four phases' columns are in the transpose tiles
     {
       float* tq = T0 + row_l * TLD + c * NT;
 #pragma unroll
@@ -337,12 +344,13 @@ __global__ __launch_bounds__(256, OCC) void quant_super_kernel(QuantSuperArgs a)
   critical_path_priority();
   constexpr int ROWS = QS<L>::ROWS, NT = QS<L>::NT, TLD = QS<L>::TLD, UBUF = QS<L>::UBUF, UD = QS<L>::UD, CLD = QS<L>::CLD;
   extern __shared__ __attribute__((aligned(16))) float qs_lds[];
-  float* Us = qs_lds;                                          // [2][UBUF]
-  float* Ud = Us + 2 * UBUF;                                   // [2][UD]
-  uint8_t* T1b = reinterpret_cast<uint8_t*>(Ud + 2 * UD);      // [ROWS][CLD]
+  constexpr int NBUF = QS<L>::NBUF;
+  float* Us = qs_lds;                                          // [NBUF][UBUF]
+  float* Ud = Us + NBUF * UBUF;                                // [NBUF][UD]
+  float* T0 = Ud + NBUF * UD;                                  // [ROWS][TLD] Q1 of the block, then Q1 - W0 (the update's A operand)
+  uint8_t* T1b = reinterpret_cast<uint8_t*>(T0 + ROWS * TLD);  // [ROWS][CLD] codes
   int* grp = reinterpret_cast<int*>(T1b + ROWS * CLD);         // [128]
   int* cmap = grp + 128;                                       // [128]
-  float* T0 = Us + UBUF;                                       // [ROWS][TLD] over U buffer 1 (dead between phase 3 and the next phase 0's end)
 
   const int tid0 = threadIdx.x;
   const int c0 = tid0 % L, row_l0 = tid0 / L;
@@ -376,7 +384,7 @@ __global__ __launch_bounds__(256, OCC) void quant_super_kernel(QuantSuperArgs a)
       cmap[tid] = a.col_map ? a.col_map[i1 + tid] : i1 + tid;
     }
     __syncthreads();                                           // grp / cmap; the previous block's updates of W are visible
-    float w[NT], cd[NT], psc[NT], pzr[NT];
+    float w[NT], psc[NT], pzr[NT];
     const float* wrow = a.W + rbase * a.ldw + i1;
 #pragma unroll
     for (int t = 0; t < NT; ++t) w[t] = wrow[L * t + c];
@@ -388,27 +396,25 @@ __global__ __launch_bounds__(256, OCC) void quant_super_kernel(QuantSuperArgs a)
         pzr[t] = a.zero_tab[rbase * a.tab_ld + g];
       }
     }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) cd[t] = 0.f;
     float loss = 0.f;
     const bool have_next = b + 1 < a.nb;
     QS_STAMP(1);
-    qs_phase<L, GROUPED, 0>(a, i1 + 128, have_next, w, cd, psc, pzr, sc, zr, Us, Ud, i1, c, base4, swz, tid, loss);
+    qs_phase<L, GROUPED, 0>(a, i1 + 128, have_next, w, psc, pzr, sc, zr, Us, Ud, T0, T1b, cmap, i1, c, row_l, rbase, active, base4, swz, tid, loss);
     QS_STAMP(2);
-    qs_phase<L, GROUPED, 1>(a, i1 + 128, have_next, w, cd, psc, pzr, sc, zr, Us, Ud, i1, c, base4, swz, tid, loss);
+    qs_phase<L, GROUPED, 1>(a, i1 + 128, have_next, w, psc, pzr, sc, zr, Us, Ud, T0, T1b, cmap, i1, c, row_l, rbase, active, base4, swz, tid, loss);
     QS_STAMP(3);
-    qs_phase<L, GROUPED, 2>(a, i1 + 128, have_next, w, cd, psc, pzr, sc, zr, Us, Ud, i1, c, base4, swz, tid, loss);
+    qs_phase<L, GROUPED, 2>(a, i1 + 128, have_next, w, psc, pzr, sc, zr, Us, Ud, T0, T1b, cmap, i1, c, row_l, rbase, active, base4, swz, tid, loss);
     QS_STAMP(4);
-    qs_phase<L, GROUPED, 3>(a, i1 + 128, have_next, w, cd, psc, pzr, sc, zr, Us, Ud, i1, c, base4, swz, tid, loss);
+    qs_phase<L, GROUPED, 3>(a, i1 + 128, have_next, w, psc, pzr, sc, zr, Us, Ud, T0, T1b, cmap, i1, c, row_l, rbase, active, base4, swz, tid, loss);
     QS_STAMP(5);
     loss_row += 0.5f * loss;                                   // gptq.py:274
 
     {
       const int nrem = a.nb - 1 - b;                           // (workgroup-uniform)
-      if (nrem == 3) qs_retire<L, 3>(a, w, cd, T0, T1b, cmap, i1, b, c, row_l, row0, rbase, active, tid);
-      else if (nrem == 2) qs_retire<L, 2>(a, w, cd, T0, T1b, cmap, i1, b, c, row_l, row0, rbase, active, tid);
-      else if (nrem == 1) qs_retire<L, 1>(a, w, cd, T0, T1b, cmap, i1, b, c, row_l, row0, rbase, active, tid);
-      else qs_retire<L, 0>(a, w, cd, T0, T1b, cmap, i1, b, c, row_l, row0, rbase, active, tid);
+      if (nrem == 3) qs_retire<L, 3>(a, T0, T1b, i1, b, c, row_l, row0, rbase, active, tid);
+      else if (nrem == 2) qs_retire<L, 2>(a, T0, T1b, i1, b, c, row_l, row0, rbase, active, tid);
+      else if (nrem == 1) qs_retire<L, 1>(a, T0, T1b, i1, b, c, row_l, row0, rbase, active, tid);
+      else qs_retire<L, 0>(a, T0, T1b, i1, b, c, row_l, row0, rbase, active, tid);
     }
     QS_STAMP(7);
   }
@@ -432,9 +438,11 @@ int quant_super_lanes(int R) {
   const char* e = getenv("GPTQ_QS_LANES");                 // (read per call: tests switch paths inside one process)
   const int env = e ? atoi(e) : -1;
   if (env == 0 || env == 8 || env == 16) return env;
-  // measured (solve of R x 4096, act-order): 4096 rows 4.23 -> 3.78 ms, 12288 6.42 -> 6.00 (8 lanes), 16384 7.37 -> 7.06, 22016
-  // 8.62 -> 8.84: beyond 16384 rows the 8-lane kernel needs two rounds of workgroups (256 registers: two per compute unit)
-  return R <= 8192 ? 16 : R <= 16384 ? 8 : 0;
+  // measured (solve of R x 4096, act-order, per-block path -> this kernel): 4096 rows 4.23 -> 3.77 ms (16 lanes); 12288
+  // 6.54 -> 6.05, 16384 7.51 -> 6.91, 22016 8.95 -> 8.75 (8 lanes, two workgroups per compute unit; three per compute unit
+  // -- 168 registers, one U-row buffer -- measured SLOWER, 9.70: three 40 KB workgroups leave no room for the helper
+  // stream's 67 KB update tiles, the two streams then take turns instead of sharing the chip)
+  return R <= 8192 ? 16 : R <= 24576 ? 8 : 0;
 }
 
 // Launch for one super-block.  Preconditions (checked by the caller, gptq_fasterquant_rows): factor form, 16-byte
