@@ -278,6 +278,32 @@ def _sharding_case(kind):
     return model, calib, QuantArgs(wbits=4, nsamples=7, act_order=True, true_sequential=True), "llama"
 
 
+@pytest.mark.parametrize("kind", ["opt_g32", "llama_actorder_trueseq"])
+def test_driver_prefetch_and_early_exit_change_nothing(hip_device, kind):
+    """The driver's own additions -- blocks uploaded / downloaded on a copy stream, hooked calibration passes left once
+    every Linear of the group has fired its hook -- against the reference's flow (blocks moved on the compute stream,
+    full passes, opt.py:104-219): same hook inputs, same kernels, so the quantized model must be bit-identical and the
+    per-Linear errors equal."""
+    import gptq_amd.gptq as gmod
+    from gptq_amd.sequential import llama_sequential, opt_sequential, quantize_sequential
+    gmod.VERBOSE = False
+    out = {}
+    for mode in (False, True):
+        model, calib, args, seq = _sharding_case(kind)
+        args.prefetch_blocks = args.early_exit = mode
+        tm = {}
+        quantize_sequential(model, calib, hip_device, args, timings=tm)
+        assert all(p.device.type == "cpu" for p in model.parameters())          # every block is back on the host
+        out[mode] = ({k: v.clone() for k, v in model.state_dict().items()},
+                     [r["error"] for r in quantize_sequential.last_records], tm)
+    (sd0, e0, t0), (sd1, e1, t1) = out[False], out[True]
+    assert e0 == e1
+    assert sd0.keys() == sd1.keys() and all(torch.equal(sd0[k], sd1[k]) for k in sd0)
+    for tm in (t0, t1):
+        assert tm["blocks"] == 2 and tm["wall_s"] > 0 and tm["solve"] > 0 and tm["hessian"] > 0
+        assert {"transfer", "forward_hooked", "forward_final"} <= set(tm)
+
+
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("kind", ["opt_g32", "llama_actorder_trueseq"])
 def test_data_parallel_two_ranks_match_single_process(hip_device, tmp_path, kind):
