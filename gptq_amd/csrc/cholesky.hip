@@ -129,9 +129,15 @@ __device__ __forceinline__ void acc_store(const f32x16& acc, float* T, int ld, i
 // chain takes ~2.5 us instead of ~7 us with v_readlane broadcasts of every multiplier (+ ~1.5 us for the inverse).
 // The sub-panel below D is then a plain product with D^-1 (MFMA) instead of a per-row substitution.
 // ---------------------------------------------------------------------------------------------
+// Round 3: the two recurrences of a column step run on TWO waves.  Wave 0 keeps the factorization (D -= l l^T) and
+// publishes every column's l and 1 / l_jj through LDS; wave 1, a step behind on another SIMD, carries the inverse
+// (M -= l x_j^T).  In one wave the two dependent MFMAs of a step cost 350 cycles, the factorization alone 250 (round-2
+// stamps): wave 1 needs no more than that per step, so the chain of 32 columns ends ~100 cycles after wave 0's.
+// Hand-off: wave 0's three LDS stores of a step (l, 1 / l_jj, step counter) are volatile, hence issued in this order,
+// and the LDS executes one wave's instructions in order: a reader that has seen the counter reads the step's data.
 template <int J>
-__device__ __forceinline__ void factor32_step(f32x16& S, f32x16& M, float* Xd, int ldx, float* Ld, int& bad, int c,
-                                              int lane) {
+__device__ __forceinline__ void factor32_stepD(f32x16& S, float* Ld, volatile float* invs, volatile int* step, int base,
+                                               int& bad, int c, int lane) {
   constexpr int e = (J & 3) + 4 * (J >> 3);       // register holding row J
   constexpr int h = (J >> 2) & 1;                 // half of the wave holding row J
   const float srow = S[e];                        // (a copy: __builtin_bit_cast of a vector ELEMENT reads element 0)
@@ -142,19 +148,48 @@ __device__ __forceinline__ void factor32_step(f32x16& S, f32x16& M, float* Xd, i
   // 1/sqrt by v_rsq_f32 + one Newton step, l_jj = a_jj * that (tolerance-level, like the rest of the chain)
   float inv = __builtin_amdgcn_rsqf(ajj);
   inv = inv * __builtin_fmaf(-0.5f * ajj * inv, inv, 1.5f);
-  // `c` is laundered by the caller once per step, so that the 64 lane masks (c >= J, c > J) are compared here, in the
-  // shadow of the MFMAs, instead of being hoisted out of the 32 steps into scalar registers that spill
+  // `c` is laundered by the caller once per step, so that the 64 lane masks (c >= J) are compared here, in the shadow of
+  // the MFMA, instead of being hoisted out of the 32 steps into scalar registers that spill
   const bool mine = (lane >> 5) == h;
   const float l = (mine && c >= J) ? srow * inv : 0.f;          // column J of L_D, l_J = sqrt(a_JJ)
-  const float x = mine ? M[e] * inv : 0.f;                      // row J of L_D^-1 (exact zeros right of the diagonal)
-  // both halves store (the idle half into a scratch row / column behind the images): no exec-mask branch per step
-  *(mine ? Xd + J * ldx + c : Ld + 32 * 33 + c) = x;            // (32 scratch floats behind Ld)
-  Ld[c * 33 + (mine ? J : 32)] = l;                             // column J of L_D; column 32 of the 33-wide buffer is scratch
-  const float ls = (c > J) ? l : 0.f;
+  // both halves store (the idle half into the scratch column 32 of the 33-wide buffer): no exec-mask branch per step
+  // plain stores kept in program order by compiler barriers (volatile ones are each followed by s_waitcnt lgkmcnt(0): an
+  // LDS round trip per store on the chain -- measured 500 instead of 250 cycles per step); the hardware keeps the order
+  Ld[c * 33 + (mine ? J : 32)] = l;
+  const_cast<float*>(invs)[J] = inv;
+  asm volatile("" ::: "memory");
+  *const_cast<int*>(step) = base + J + 1;
+  asm volatile("" ::: "memory");
   S = __builtin_amdgcn_mfma_f32_32x32x2f32(-l, l, S, 0, 0, 0);
-#ifdef GPTQ_DIAG
-  if (bad < 0) return;                                          // timing-only ablation: no inverse (see potrf_phases.py)
-#endif
+}
+// Wave 1's view of a column: the step counter FIRST, then the column's data -- issued back to back, executed by the
+// LDS in that order, so data that travels with a counter value >= its step is the published data (one LDS round trip
+// per step instead of two; the read for column J + 1 is issued before column J's MFMA).
+struct ColView { int sv; float l, inv; };
+template <int J>
+__device__ __forceinline__ void col_fetch(ColView& v, float* Ld, volatile float* invs, volatile int* step, int c) {
+  asm volatile("" ::: "memory");
+  v.sv = *const_cast<int*>(step);
+  asm volatile("" ::: "memory");                                // (the counter's read is issued before the data's)
+  v.l = Ld[c * 33 + J];
+  v.inv = const_cast<float*>(invs)[J];
+  asm volatile("" ::: "memory");
+}
+template <int J>
+__device__ __forceinline__ void factor32_stepM(f32x16& M, float* Xd, int ldx, float* Ld, volatile float* invs,
+                                               volatile int* step, int base, int c, int lane, ColView& v) {
+  constexpr int e = (J & 3) + 4 * (J >> 3);
+  constexpr int h = (J >> 2) & 1;
+  while (v.sv < base + J + 1) {                                 // (wave 0 of this workgroup always gets there)
+    __builtin_amdgcn_s_sleep(0);
+    col_fetch<J>(v, Ld, invs, step, c);
+  }
+  const float l = v.l, inv = v.inv;                             // column J of L_D (rows c), 1 / l_JJ
+  if constexpr (J < 31) col_fetch<J + 1>(v, Ld, invs, step, c); // speculative: checked by the next step
+  const bool mine = (lane >> 5) == h;
+  const float x = mine ? M[e] * inv : 0.f;                      // row J of L_D^-1 (exact zeros right of the diagonal)
+  *(mine ? Xd + J * ldx + c : Ld + 32 * 33 + c) = x;            // (the idle half: 32 scratch floats behind Ld)
+  const float ls = (mine && c > J) ? l : 0.f;
   M = __builtin_amdgcn_mfma_f32_32x32x2f32(-ls, x, M, 0, 0, 0);
 }
 
@@ -176,6 +211,8 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
   float* S = dsm;                       // [128][129]  A_kk (full, mirrored) -> L off-diagonal blocks -> L_kk^-1
   float* Tt = S + 64;                   // [64][LD]    level-2 intermediate, in the dead quadrant S[0:64, 64:128]
   float* Ld = S + NB * LD;              // [32][33]    factor of the current diagonal 32 x 32 sub-block (+ 32 scratch floats)
+  volatile float* invs = Ld + 32 * 33 + 32;                       // [32] 1 / l_jj of the current sub-block (wave 0 -> wave 1)
+  volatile int* step = reinterpret_cast<volatile int*>(Ld + 32 * 33 + 64);   // columns published so far (monotonic)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* Ak = A + (long)kb * NB * Cp + (long)kb * NB;
@@ -200,6 +237,7 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
       }
     }
   }
+  if (tid == 0) *step = 0;
   __syncthreads();
   POTRF_STAMP(1);
   POTRF_STAMP(2);
@@ -208,25 +246,33 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
 #pragma unroll 1
   for (int s = 0; s < 4; ++s) {
     const int o = 32 * s;
-    if (wave == 0) {                                            // (A1) D = L_D L_D^T and X_D = L_D^-1 on the matrix cores
-      f32x16 D, M;
+    if (wave == 0) {                                            // (A1) D = L_D L_D^T on the matrix cores ...
+      f32x16 D;
       acc_load(D, S + o * LD + o, LD, lane);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) M[e] = ((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) == (lane & 31)) ? 1.f : 0.f;
-      float* Xd = S + o * LD + o;                               // X_D takes D's place (D lives in registers now)
       const int c0 = kb * NB + o;
       int bad = 0, cl = lane & 31;
-#ifdef GPTQ_DIAG
-      if (kb < 0) bad = -1;                                     // (never true: keeps `bad < 0` opaque) ...
-      if (potrf_ablate) bad = -1;
-#endif
-#define FSTEP(J) asm volatile("" : "+v"(cl)); factor32_step<J>(D, M, Xd, LD, Ld, bad, cl, lane)
+#define FSTEP(J) asm volatile("" : "+v"(cl)); factor32_stepD<J>(D, Ld, invs, step, 32 * s, bad, cl, lane)
       FSTEP(0); FSTEP(1); FSTEP(2); FSTEP(3); FSTEP(4); FSTEP(5); FSTEP(6); FSTEP(7);
       FSTEP(8); FSTEP(9); FSTEP(10); FSTEP(11); FSTEP(12); FSTEP(13); FSTEP(14); FSTEP(15);
       FSTEP(16); FSTEP(17); FSTEP(18); FSTEP(19); FSTEP(20); FSTEP(21); FSTEP(22); FSTEP(23);
       FSTEP(24); FSTEP(25); FSTEP(26); FSTEP(27); FSTEP(28); FSTEP(29); FSTEP(30); FSTEP(31);
 #undef FSTEP
       if (bad && lane == 0 && info) atomicCAS(info, 0, c0 + bad);
+    } else if (wave == 1) {                                     // ... and X_D = L_D^-1 one step behind, on another SIMD
+      f32x16 M;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) M[e] = ((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) == (lane & 31)) ? 1.f : 0.f;
+      float* Xd = S + o * LD + o;                               // X_D takes D's place (wave 0 holds D in registers by now)
+      int cl = lane & 31;
+      // (wave 0 reads D out of the image before its first step publishes anything: D's image is dead once step 1 is seen)
+      ColView cv;
+      col_fetch<0>(cv, Ld, invs, step, cl);
+#define MSTEP(J) asm volatile("" : "+v"(cl)); factor32_stepM<J>(M, Xd, LD, Ld, invs, step, 32 * s, cl, lane, cv)
+      MSTEP(0); MSTEP(1); MSTEP(2); MSTEP(3); MSTEP(4); MSTEP(5); MSTEP(6); MSTEP(7);
+      MSTEP(8); MSTEP(9); MSTEP(10); MSTEP(11); MSTEP(12); MSTEP(13); MSTEP(14); MSTEP(15);
+      MSTEP(16); MSTEP(17); MSTEP(18); MSTEP(19); MSTEP(20); MSTEP(21); MSTEP(22); MSTEP(23);
+      MSTEP(24); MSTEP(25); MSTEP(26); MSTEP(27); MSTEP(28); MSTEP(29); MSTEP(30); MSTEP(31);
+#undef MSTEP
     }
     __syncthreads();
     POTRF_STAMP(3 + 3 * s);
@@ -329,7 +375,7 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
   }
   POTRF_STAMP(16);
 }
-constexpr size_t POTRF_LDS = sizeof(float) * (NB * (NB + 1) + 32 * 33 + 32);
+constexpr size_t POTRF_LDS = sizeof(float) * (NB * (NB + 1) + 32 * 33 + 32 + 32 + 4);
 
 
 // Panel:  P <- P * inv(L_kk)^T  for the block column kb below the diagonal (rows (kb+1)*128 ...), IN PLACE.

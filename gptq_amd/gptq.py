@@ -7,7 +7,9 @@ column loop, trailing updates) is a gfx950 kernel behind the C ABI in include/gp
 """
 from __future__ import annotations
 
+import functools
 import math
+import threading
 import time
 import weakref
 
@@ -44,6 +46,22 @@ HESSIAN_DEFER = 1
 # back to the driver (a device-wide synchronisation + re-allocation on the next Linear).  With 288 GB of HBM3E
 # the cache is kept by default; set True for the reference's behaviour when memory is tight.
 EMPTY_CACHE_ON_FREE = False
+
+# The registries below (who holds deferred inputs, who shares a Hessian with whom, the solve streams) are process-wide.
+# The reference's drivers are single-threaded; callers that drive several models from several Python threads are
+# serialised on this lock around every entry point that reads or rewires the registries (add_batch, flush_pending,
+# fasterquant / fasterquant_many up to the point where the work is enqueued, free).  GPU work itself is only ENQUEUED
+# under the lock.  The knobs (HESSIAN_DEFER, LAZY_HESSIANS, ...) stay module attributes: set them before threads start.
+_STATE_LOCK = threading.RLock()
+
+
+def _locked(fn):
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        with _STATE_LOCK:
+            return fn(*args, **kwargs)
+    return wrapper
+
 
 _DIRTY = weakref.WeakValueDictionary()   # id -> GPTQ objects holding deferred hook inputs (dropped objects vanish)
 _LIVE = weakref.WeakSet()                # GPTQ objects whose Hessian is still being accumulated
@@ -156,6 +174,7 @@ def _launch_flush(work, n_cu=0):
             _DIRTY.pop(id(o), None)
 
 
+@_locked
 def flush_pending(heavy_only=False):
     """Fold deferred hook inputs into their H on the current stream.  heavy_only (LAZY_HESSIANS): only the widest
     Linears' (>= half the largest in_features among those waiting); the others keep collecting inputs."""
@@ -183,6 +202,7 @@ SOLVE_STREAMS = 3     # concurrent solves per device: the caller's stream (it ca
                       # streams beyond the queues serialize falsely
 
 
+@_locked
 def fasterquant_many(solvers, blocksize=128, percdamp=.01, groupsize=-1, actorder=False, static_groups=False,
                      max_concurrent=None):
     """`fasterquant` for several GPTQ objects at once (the `for name in subset:` loop of opt.py:189-214).
@@ -487,6 +507,7 @@ class GPTQ:
         flush_pending()
 
     @property
+    @_locked
     def H(self):
         self._flush()
         self._materialize()
@@ -517,6 +538,7 @@ class GPTQ:
             self._leader = None
         self._H = None
 
+    @_locked
     def add_batch(self, inp, out):
         """Running-mean Hessian update (gptq.py:38-65): H <- H*n/(n+b) + 2/(n+b) X^T X."""
         if DEBUG:
@@ -580,6 +602,7 @@ class GPTQ:
         if TRACK_INPUT_MEAN:   # fork addition (gptq.py:63), unused by the default branch
             self.input = x.mean(0, dtype=torch.float32) * math.sqrt(2 / self.nsamples)
 
+    @_locked
     def fasterquant(self, blocksize=128, percdamp=.01, groupsize=-1, actorder=False, static_groups=False,
                     model_name="opt", layer_name="layer", lut_quant=False, non_linear_quant=False,
                     columnwise=False):
@@ -622,6 +645,7 @@ class GPTQ:
         """Wait for the solve and publish its results."""
         _publish_rows(self, st, 0, st["W"].shape[0], _check_solved(st))
 
+    @_locked
     def free(self):
         if DEBUG:
             self.inp1 = None
