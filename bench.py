@@ -456,7 +456,18 @@ def projection(blk, n_gpus, hessian_ms, dev):
             del X
         plan = par.plan_rows(shapes, n_gpus)
         load = [0.0] * n_gpus
-        for (chain, per_row), slabs in zip(fits, plan):
+        shard_note = []
+        for bi, ((chain, per_row), slabs) in enumerate(zip(fits, plan)):
+            k, (c, R) = len(slabs), shapes[bi]
+            if par.SHARD_CHOL and k > 1 and c >= par.SHARD_CHOL_MIN_C and c % 128 == 0:
+                # the factorization itself is spread over the bundle's k ranks (parallel.rfactor_sharded): its rank-512
+                # updates (timed here call by call on this one GPU) divide by k, its serial panels do not, and every
+                # outer panel is broadcast once (C^2 / 2 floats in all, at 300 GB/s)
+                g_ms = _time_chol_updates(c, dev)
+                bcast_ms = (c * c / 2 * 4) / 300e9 * 1e3
+                shard_note.append({"C": c, "ranks": k, "replicated_chain_ms": round(chain, 2), "far_updates_ms": round(g_ms, 2),
+                                   "sharded_chain_ms": round(chain - g_ms + g_ms / k + bcast_ms, 2), "broadcast_ms": round(bcast_ms, 2)})
+                chain = chain - g_ms + g_ms / k + bcast_ms
             for (rk, a, e) in slabs:
                 load[rk] += chain + per_row * (e - a)
         trap = sum(par.tri_numel(c) * 4 for c, _ in shapes)
@@ -466,11 +477,43 @@ def projection(blk, n_gpus, hessian_ms, dev):
         exch += ex
         detail.append({"bundles": [{"C": c, "rows": R, "chain_ms": round(f[0], 2), "ms_per_1k_rows": round(f[1] * 1e3, 3),
                                     "ranks": len(sl)} for (c, R), f, sl in zip(shapes, fits, plan)],
+                       "sharded_factorizations": shard_note,
                        "solve_ms": round(max(load), 2), "exchange_ms": round(ex, 2)})
     return {"n_gpus": n_gpus, "ms_per_step": round(total, 2), "mparams_per_s": round(blk.params / total / 1e3, 1),
             "hessian_ms": round(hessian_ms / n_gpus, 2), "exchange_ms": round(exch, 2), "groups": detail,
-            "basis": "measured on 1 GPU: per distinct Hessian the solve at R and R/2 rows (chain replicated, rows split by "
-                     "parallel.plan_rows), Hessian time / n (samples sharded), exchanges at 300 GB/s per GPU; NOT a hardware number"}
+            "basis": "measured on 1 GPU: per distinct Hessian the solve at R and R/2 rows (rows split by parallel.plan_rows; the "
+                     "chain replicated, or -- bundles on several ranks -- its rank-512 updates, timed call by call, divided by "
+                     "the ranks + one broadcast per outer panel), Hessian time / n (samples sharded), exchanges at 300 GB/s per "
+                     "GPU; NOT a hardware number"}
+
+
+def _time_chol_updates(C, dev):
+    """Milliseconds the rank-512 updates of ONE factorization of width C take on this GPU: the part of the chain that
+    gptq_amd.parallel.rfactor_sharded divides among the ranks of a bundle (gptq_chol_update, timed call by call)."""
+    from gptq_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator(device=dev).manual_seed(3)
+    X = torch.randn(2048, C, device=dev, generator=gen)
+    H = (X.t() @ X) * (2.0 / 2048)
+    H.diagonal().add_(1.0)
+    nbytes = lib.gptq_hinv_workspace_bytes(C)
+    ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    info = torch.zeros(1, device=dev, dtype=torch.int32)
+    st = _lib.stream(dev)
+    nblk = C // 128
+    evs = []
+    _lib.call("gptq_chol_begin", _lib.ptr(H), H.stride(0), C, 0.01, None, _lib.ptr(info), _lib.ptr(ws), nbytes, st)
+    for p0 in range(0, nblk, 4):
+        _lib.call("gptq_chol_panel", _lib.ptr(ws), C, p0, _lib.ptr(info), st)
+        if p0 + 4 < nblk:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            _lib.call("gptq_chol_update", _lib.ptr(ws), C, p0, p0 + 4, nblk, st)
+            b.record()
+            evs.append((a, b))
+    torch.cuda.synchronize()
+    assert int(info.item()) == 0
+    return sum(a.elapsed_time(b) for a, b in evs)
 
 
 def end_to_end(dev, blocks, nsamples, hessian_defer):

@@ -39,6 +39,13 @@ _SIGNATURES = {
                                    _p, _p, _p, _z, _p]),
     "gptq_fasterquant_rows": (C.c_int, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _p, _p, _i, _p, _p, _p, _p,
                                         _p, _p, _p, _p, _z, _p]),
+    "gptq_chol_begin": (C.c_int, [_p, _i, _i, _f, _p, _p, _p, _z, _p]),
+    "gptq_chol_panel": (C.c_int, [_p, _i, _i, _p, _p]),
+    "gptq_chol_update": (C.c_int, [_p, _i, _i, _i, _i, _p]),
+    "gptq_chol_end": (C.c_int, [_p, _i, _i, _p, _p]),
+    "gptq_solve_prepare": (C.c_int, [_p, _i, _i, _i, _p, _p, _p, _p]),
+    "gptq_fasterquant_rows_factored": (C.c_int, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p, _p, _p,
+                                                _p, _p, _p, _p, _p, _p, _z, _p]),
     "gptq_pack_weights": (C.c_int, [_p, _i, _i, _i, _i, _p, _p, _i, _p, _p]),
     "gptq_pack_codes": (C.c_int, [_p, _i, _i, _i, _i, _p, _p]),
     "gptq_dequant_packed": (C.c_int, [_p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _p]),

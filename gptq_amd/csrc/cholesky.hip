@@ -690,6 +690,85 @@ extern "C" int gptq_diag_potrf_stamps(unsigned long long* out17) {
 }
 #endif
 
+// ---------------------------------------------------------------------------------------------
+// The factor-form chain in pieces, for a factorization whose OUTER PANELS are spread over several GPUs (the reference has
+// no counterpart: SURVEY 8e; gptq_amd/parallel.py::rfactor_sharded drives them).  All ranks hold the same H and call
+// `begin`; outer panel j (block columns 4j .. 4j + 3) belongs to one rank, which factorizes it with `panel` once its
+// columns carry the updates of all earlier panels, and broadcasts it (the host's collective library); every rank applies
+// `update` to the block columns IT owns; `end` forms Rt / U_kk in H like gptq_rfactor_upper.  With one rank the sequence
+// begin, {panel(j), update(j, everything beyond)}..., end IS gptq_rfactor_upper (same kernels, no helper stream).
+// Workspace: gptq_hinv_workspace_bytes(C); A = [Cp, Cp] floats at offset 0, the diagonal blocks' inverses in Linv =
+// [Cp, Cp] floats at offset Cp * Cp * 4 (Cp = C rounded up to 128: both offsets are 256-byte aligned).
+// ---------------------------------------------------------------------------------------------
+static int chol_ws(void* workspace, int C, float** A, float** Linv, float** damp) {
+  GPTQ_CHECK_ARG(workspace && C > 0 && C % NB == 0, "gptq_chol_*: C must be a positive multiple of 128");
+  GPTQ_CHECK_ARG(reinterpret_cast<uintptr_t>(workspace) % 256 == 0, "gptq_chol_*: workspace must be 256-byte aligned");
+  Carver cv(workspace);
+  *A = cv.take<float>((size_t)C * C);
+  *Linv = cv.take<float>((size_t)C * C);
+  *damp = cv.take<float>(64);
+  return GPTQ_OK;
+}
+
+extern "C" int gptq_chol_begin(float* H, int ldh, int C, float percdamp, const int32_t* perm, int32_t* info,
+                               void* workspace, size_t workspace_bytes, gptq_stream_t stream) {
+  GPTQ_CHECK_ARG(H && ldh >= C, "gptq_chol_begin: bad arguments");
+  GPTQ_CHECK_ARG(workspace_bytes >= gptq_hinv_workspace_bytes(C), "gptq_chol_begin: workspace too small");
+  float *A, *Linv, *damp;
+  if (int rc = chol_ws(workspace, C, &A, &Linv, &damp)) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  diag_mean_kernel<<<1, 256, 0, s>>>(H, ldh, C, percdamp, damp, info);
+  build_abar_kernel<<<dim3(cdiv(C, 256), C), 256, 0, s>>>(H, ldh, C, C, perm, damp, A);
+  GPTQ_CHECK_LAUNCH("gptq_chol_begin");
+  return GPTQ_OK;
+}
+
+extern "C" int gptq_chol_panel(void* workspace, int C, int p0, int32_t* info, gptq_stream_t stream) {
+  float *A, *Linv, *damp;
+  if (int rc = chol_ws(workspace, C, &A, &Linv, &damp)) return rc;
+  const int nblk = C / NB;
+  GPTQ_CHECK_ARG(p0 >= 0 && p0 < nblk && p0 % CSUPER == 0, "gptq_chol_panel: p0 must be the first block of an outer panel");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_inv_diag_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_LDS));
+  const int p1 = std::min(p0 + CSUPER, nblk);
+  for (int kb = p0; kb < p1; ++kb) {
+    potrf_inv_diag_kernel<<<1, 512, POTRF_LDS, s>>>(A, Linv, C, kb, info);
+    const int nrem = nblk - kb - 1;
+    if (nrem <= 0) break;
+    panel_kernel<<<2 * nrem, GEMM_THREADS, 0, s>>>(A, Linv, C, kb);
+    if (kb + 1 < p1)
+      syrk_kernel<<<dim3(syrk_tiles(nblk, kb + 1, p1), 4), GEMM_THREADS, 0, s>>>(A, C, nblk, kb * NB, NB, kb + 1, p1);
+  }
+  GPTQ_CHECK_LAUNCH("gptq_chol_panel");
+  return GPTQ_OK;
+}
+
+extern "C" int gptq_chol_update(void* workspace, int C, int p0, int tn0, int tn1, gptq_stream_t stream) {
+  float *A, *Linv, *damp;
+  if (int rc = chol_ws(workspace, C, &A, &Linv, &damp)) return rc;
+  const int nblk = C / NB;
+  const int p1 = std::min(p0 + CSUPER, nblk);
+  GPTQ_CHECK_ARG(p0 >= 0 && p0 < nblk && p0 % CSUPER == 0 && tn0 >= p1 && tn1 <= nblk, "gptq_chol_update: bad block range");
+  if (tn0 >= tn1) return GPTQ_OK;
+  syrk128_kernel<<<syrk_tiles(nblk, tn0, tn1), GEMM_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
+      A, C, nblk, p0 * NB, (p1 - p0) * NB, tn0, tn1);
+  GPTQ_CHECK_LAUNCH("gptq_chol_update");
+  return GPTQ_OK;
+}
+
+extern "C" int gptq_chol_end(float* H, int ldh, int C, void* workspace, gptq_stream_t stream) {
+  GPTQ_CHECK_ARG(H && ldh >= C, "gptq_chol_end: bad arguments");
+  float *A, *Linv, *damp;
+  if (int rc = chol_ws(workspace, C, &A, &Linv, &damp)) return rc;
+  const int nblk = C / NB;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (nblk > 1) rtilde_kernel<<<dim3(nblk * (nblk - 1) / 2, 4), GEMM_THREADS, 0, s>>>(A, Linv, C, nblk, C, H, ldh);
+  flip_diag_kernel<<<cdiv(C, 2), 256, 0, s>>>(Linv, C, C, H, ldh);
+  GPTQ_CHECK_LAUNCH("gptq_chol_end");
+  return GPTQ_OK;
+}
+
 extern "C" int gptq_hinv_upper(float* H, int ldh, int C, float percdamp, const int32_t* perm,
                                int32_t* info, void* workspace, size_t workspace_bytes,
                                gptq_stream_t stream) {

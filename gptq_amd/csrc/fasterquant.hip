@@ -711,12 +711,62 @@ extern "C" size_t gptq_fasterquant_workspace_bytes(int R, int C, int blocksize, 
   return carve_solve(nullptr, R, C, blocksize, groupsize, actorder, static_groups).total;
 }
 
+// The head of the solve alone (gptq.py:143-145, 166): the dead-column fix of H's diagonal and, with act-order, the
+// permutation -- what a factorization spread over several GPUs (gptq_chol_*) needs BEFORE it starts.  dead_out / perm_out:
+// [C] int32; scratch: [C] floats.
+extern "C" int gptq_solve_prepare(float* H, int ldh, int C, int actorder, int32_t* dead_out, int32_t* perm_out,
+                                  float* scratch, gptq_stream_t stream) {
+  GPTQ_CHECK_ARG(H && dead_out && scratch && C > 0 && ldh >= C && (!actorder || perm_out), "gptq_solve_prepare: bad arguments");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  dead_fix_kernel<<<cdiv(C, 256), 256, 0, s>>>(H, ldh, C, dead_out, scratch);
+  if (actorder) argsort_desc_kernel<<<cdiv(C, 64), 256, 0, s>>>(scratch, C, perm_out);
+  GPTQ_CHECK_LAUNCH("gptq_solve_prepare");
+  return GPTQ_OK;
+}
+
+static int fasterquant_rows_impl(float* W, int ldw, float* H, int ldh, int R, int C, int bits, int sym,
+                                 int blocksize, float percdamp, int groupsize, int actorder,
+                                 int static_groups, float* scale_io, float* zero_io, int preset,
+                                 float* group_scale, float* group_zero, int32_t* perm_out,
+                                 uint8_t* codes, float* error_out, float* row_loss, int32_t* info,
+                                 void* workspace, size_t workspace_bytes, gptq_stream_t stream,
+                                 const int32_t* dead_in, const int32_t* perm_in);
+
 extern "C" int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R, int C, int bits, int sym,
                                      int blocksize, float percdamp, int groupsize, int actorder,
                                      int static_groups, float* scale_io, float* zero_io, int preset,
                                      float* group_scale, float* group_zero, int32_t* perm_out,
                                      uint8_t* codes, float* error_out, float* row_loss, int32_t* info,
                                      void* workspace, size_t workspace_bytes, gptq_stream_t stream) {
+  return fasterquant_rows_impl(W, ldw, H, ldh, R, C, bits, sym, blocksize, percdamp, groupsize, actorder, static_groups,
+                               scale_io, zero_io, preset, group_scale, group_zero, perm_out, codes, error_out, row_loss, info,
+                               workspace, workspace_bytes, stream, nullptr, nullptr);
+}
+
+// gptq_fasterquant_rows for an H that ALREADY holds what gptq_rfactor_upper leaves (factor form only: see
+// gptq_fasterquant_factor_form), factorized elsewhere from the H that gptq_solve_prepare fixed, with its `dead` flags and
+// (act-order) its permutation: everything but the dead-column fix, the argsort and the factorization.
+extern "C" int gptq_fasterquant_rows_factored(float* W, int ldw, float* H, int ldh, int R, int C, int bits, int sym,
+                                              int blocksize, int groupsize, int actorder, int static_groups,
+                                              float* scale_io, float* zero_io, int preset, float* group_scale,
+                                              float* group_zero, const int32_t* dead_in, const int32_t* perm_in,
+                                              uint8_t* codes, float* error_out, float* row_loss, int32_t* info,
+                                              void* workspace, size_t workspace_bytes, gptq_stream_t stream) {
+  GPTQ_CHECK_ARG(dead_in && (!actorder || perm_in), "gptq_fasterquant_rows_factored: dead_in / perm_in missing");
+  GPTQ_CHECK_ARG(use_rform(C, blocksize, groupsize, static_groups), "gptq_fasterquant_rows_factored: factor form only");
+  return fasterquant_rows_impl(W, ldw, H, ldh, R, C, bits, sym, blocksize, 0.f, groupsize, actorder, static_groups,
+                               scale_io, zero_io, preset, group_scale, group_zero, nullptr, codes, error_out, row_loss, info,
+                               workspace, workspace_bytes, stream, dead_in, perm_in);
+}
+
+static int fasterquant_rows_impl(float* W, int ldw, float* H, int ldh, int R, int C, int bits, int sym,
+                                 int blocksize, float percdamp, int groupsize, int actorder,
+                                 int static_groups, float* scale_io, float* zero_io, int preset,
+                                 float* group_scale, float* group_zero, int32_t* perm_out,
+                                 uint8_t* codes, float* error_out, float* row_loss, int32_t* info,
+                                 void* workspace, size_t workspace_bytes, gptq_stream_t stream,
+                                 const int32_t* dead_in, const int32_t* perm_in) {
+  const bool factored = dead_in != nullptr;
   GPTQ_CHECK_ARG(W && H && scale_io && zero_io && error_out && workspace, "gptq_fasterquant: null pointer");
   GPTQ_CHECK_ARG(R > 0 && C > 0 && ldw >= C && ldh >= C, "gptq_fasterquant: bad sizes");
   GPTQ_CHECK_ARG(R <= 4000000, "gptq_fasterquant: R too large (4,000,000 rows per call)");
@@ -739,8 +789,14 @@ extern "C" int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R
   const int TB = 256;
 
   // dead columns (gptq.py:143-145)
-  dead_fix_kernel<<<cdiv(C, TB), TB, 0, s>>>(H, ldh, C, ws.dead, ws.diag);
-  if (actorder) argsort_desc_kernel<<<cdiv(C, 64), 256, 0, s>>>(ws.diag, C, ws.perm);   // gptq.py:166
+  if (factored) {                                                // (done by gptq_solve_prepare before the factorization)
+    GPTQ_CHECK_HIP(hipMemcpyAsync(ws.dead, dead_in, sizeof(int32_t) * C, hipMemcpyDeviceToDevice, s));
+    if (actorder) GPTQ_CHECK_HIP(hipMemcpyAsync(ws.perm, perm_in, sizeof(int32_t) * C, hipMemcpyDeviceToDevice, s));
+    if (info) GPTQ_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int32_t), s));
+  } else {
+    dead_fix_kernel<<<cdiv(C, TB), TB, 0, s>>>(H, ldh, C, ws.dead, ws.diag);
+    if (actorder) argsort_desc_kernel<<<cdiv(C, 64), 256, 0, s>>>(ws.diag, C, ws.perm);   // gptq.py:166
+  }
   // Everything that prepares W (dead columns zeroed, static-group grids, act-order gather, full-row grid) depends on
   // diag(H) only, not on the factorization: it runs on the helper stream beside the chain below, which is serial and
   // latency-bound and leaves the chip idle.  (No helper stream: same kernels, caller's stream.)
@@ -784,7 +840,7 @@ extern "C" int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R
                                     hipMemcpyDeviceToDevice, ps));
   if (sc) GPTQ_CHECK_HIP(hipEventRecord(sc->prep_done, sc->stream));
   // damped inverse factor (gptq.py:174-180): H <- U, or (factor form) what gptq_rfactor_upper leaves
-  {
+  if (!factored) {
     const int rc = rform ? gptq_rfactor_upper(H, ldh, C, percdamp, perm, info, ws.hinv, ws.hinv_bytes, stream)
                          : gptq_hinv_upper(H, ldh, C, percdamp, perm, info, ws.hinv, ws.hinv_bytes, stream);
     if (rc != GPTQ_OK) return rc;

@@ -328,10 +328,12 @@ def fasterquant_many(solvers, blocksize=128, percdamp=.01, groupsize=-1, actorde
         g._solve_finish(state)
 
 
-def _enqueue_rows(dev, W, H, quantizer, preset_grid, blocksize, percdamp, groupsize, actorder, static_groups):
+def _enqueue_rows(dev, W, H, quantizer, preset_grid, blocksize, percdamp, groupsize, actorder, static_groups,
+                  factored=None):
     """Enqueue one gptq_fasterquant_rows call on the CURRENT stream for the rows of `W` [R, C] (fp32, contiguous) with
     the Hessian `H` (consumed: left holding the factor, see `Hinv_form`); nothing here waits for the GPU.  `preset_grid` = (scale, zero) of a
-    ready quantizer (gptq.py:181) or None.  Returns the buffers of the call."""
+    ready quantizer (gptq.py:181) or None.  `factored` = dict(dead, perm, info): H already holds the factor form
+    (gptq_amd.parallel.rfactor_sharded) of the Hessian that gptq_solve_prepare fixed.  Returns the buffers of the call."""
     q = quantizer
     tick = time.time()
     bits = int(getattr(q, "wbits", 0)) or (int(q.maxq) + 1).bit_length() - 1
@@ -345,6 +347,8 @@ def _enqueue_rows(dev, W, H, quantizer, preset_grid, blocksize, percdamp, groups
     gscale = torch.empty((R, G), device=dev, dtype=torch.float32) if G else None
     gzero = torch.empty((R, G), device=dev, dtype=torch.float32) if G else None
     perm = torch.empty(C, device=dev, dtype=torch.int32) if actorder else None
+    if factored is not None:
+        perm = factored["perm"] if actorder else None
     codes = torch.empty((R, C), device=dev, dtype=torch.uint8)
     stat = torch.zeros(2, device=dev, dtype=torch.float32)          # [error, info (int32 bits)]
     row_loss = torch.empty(R, device=dev, dtype=torch.float32)
@@ -354,11 +358,19 @@ def _enqueue_rows(dev, W, H, quantizer, preset_grid, blocksize, percdamp, groups
                                                   int(bool(static_groups)))
     ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
     with torch.cuda.device(dev):
-        _lib.call("gptq_fasterquant_rows", _lib.ptr(W), W.stride(0), _lib.ptr(H), H.stride(0), R, C, bits,
-                  int(bool(q.sym)), int(blocksize), float(percdamp), int(groupsize), int(bool(actorder)),
-                  int(bool(static_groups)), _lib.ptr(scale), _lib.ptr(zero), int(preset_grid is not None),
-                  _lib.ptr(gscale), _lib.ptr(gzero), _lib.ptr(perm), _lib.ptr(codes), _lib.ptr(stat),
-                  _lib.ptr(row_loss), _lib.ptr(info), _lib.ptr(ws), nbytes, _lib.stream(dev))
+        if factored is None:
+            _lib.call("gptq_fasterquant_rows", _lib.ptr(W), W.stride(0), _lib.ptr(H), H.stride(0), R, C, bits,
+                      int(bool(q.sym)), int(blocksize), float(percdamp), int(groupsize), int(bool(actorder)),
+                      int(bool(static_groups)), _lib.ptr(scale), _lib.ptr(zero), int(preset_grid is not None),
+                      _lib.ptr(gscale), _lib.ptr(gzero), _lib.ptr(perm), _lib.ptr(codes), _lib.ptr(stat),
+                      _lib.ptr(row_loss), _lib.ptr(info), _lib.ptr(ws), nbytes, _lib.stream(dev))
+        else:
+            _lib.call("gptq_fasterquant_rows_factored", _lib.ptr(W), W.stride(0), _lib.ptr(H), H.stride(0), R, C, bits,
+                      int(bool(q.sym)), int(blocksize), int(groupsize), int(bool(actorder)), int(bool(static_groups)),
+                      _lib.ptr(scale), _lib.ptr(zero), int(preset_grid is not None), _lib.ptr(gscale), _lib.ptr(gzero),
+                      _lib.ptr(factored["dead"]), _lib.ptr(perm), _lib.ptr(codes), _lib.ptr(stat), _lib.ptr(row_loss),
+                      _lib.ptr(info), _lib.ptr(ws), nbytes, _lib.stream(dev))
+            info.copy_(factored["info"])          # a non-positive pivot of the (sharded) factorization
     form = lib.gptq_fasterquant_factor_form(C, int(blocksize), int(groupsize), int(bool(static_groups)))
     return dict(tick=tick, W=W, H=H, scale=scale, zero=zero, gscale=gscale, gzero=gzero, perm=perm, codes=codes,
                 stat=stat, ws=ws, row_loss=row_loss, static_groups=bool(static_groups),

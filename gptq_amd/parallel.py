@@ -105,6 +105,100 @@ def allgather_payload(send: torch.Tensor, group=None) -> torch.Tensor:
     return recv
 
 
+# ------------------------------------------------------------------------------------------------
+# Factorization spread over the ranks of a bundle: outer panels dealt cyclically, one broadcast per panel
+# ------------------------------------------------------------------------------------------------
+# A bundle's factorization chain depends on H only, so fasterquant_sharded used to REPLICATE it on every rank that owns
+# rows of the bundle -- for LLaMA-65B's down_proj (C = 22016) that is 43 of its 48 ms, of which 39 ms are the rank-512
+# updates (C^3 / 3 flop).  With SHARD_CHOL the outer panels (512 columns) of the factorization are dealt to the bundle's
+# ranks cyclically: the owner factorizes its panel (gptq_chol_panel), broadcasts it (rows below x 512 floats + four
+# 128 x 128 inverses: C^2 / 2 floats per factorization in all), every rank updates the block columns of ITS panels
+# (gptq_chol_update).  The serial chain (4 diagonal blocks per panel) stays serial; the GEMM flops divide by the ranks.
+# Same kernels and the same ascending k order as gptq_rfactor_upper: the factor is bit-identical to the single-rank one.
+SHARD_CHOL = __import__("os").environ.get("GPTQ_SHARD_CHOL", "1") != "0"
+SHARD_CHOL_MIN_C = 4096          # below, a chain is a few ms and the 8 + broadcasts per factorization cost more than they save
+_SUBGROUPS = {}
+
+
+def _bcast(t: torch.Tensor, src_global: int, group=None) -> None:
+    if t.is_cuda and dist.get_backend(group) != "nccl":         # rehearsal backends (gloo): stage through the host
+        host = t.cpu()
+        dist.broadcast(host, src_global, group=group)
+        t.copy_(host)
+    else:
+        dist.broadcast(t, src_global, group=group)
+
+
+def _subgroup(ranks: Sequence[int], group=None):
+    """Process group of `ranks` (ranks OF `group`).  EVERY rank of `group` must call this, in the same order (new_group
+    is collective); cached."""
+    world = dist.get_world_size(group)
+    if len(ranks) == world:
+        return group
+    glob = tuple(dist.get_global_rank(group, r) if group is not None else r for r in ranks)
+    if glob not in _SUBGROUPS:
+        _SUBGROUPS[glob] = dist.new_group(ranks=list(glob))
+    return _SUBGROUPS[glob]
+
+
+def rfactor_sharded(H: torch.Tensor, perm, percdamp: float, ranks: Sequence[int], group=None, sub=None) -> torch.Tensor:
+    """H [C, C] (dead-column fix applied, identical on all `ranks` of `group`) <- what gptq_rfactor_upper leaves in it,
+    the outer panels of the factorization dealt over `ranks` (this rank among them).  `sub`: the process group of exactly
+    `ranks` (`_subgroup`).  Returns the device int32[1] pivot flag (non-zero: not positive-definite)."""
+    from . import _lib
+    dev = H.device
+    C = H.shape[0]
+    assert C % 128 == 0 and H.stride(0) >= C
+    nblk = C // 128
+    lib = _lib.load()
+    nbytes = lib.gptq_hinv_workspace_bytes(C)
+    ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    A = ws[:C * C * 4].view(torch.float32).view(C, C)
+    Linv = ws[C * C * 4:2 * C * C * 4].view(torch.float32).view(C, C)
+    info = torch.zeros(1, device=dev, dtype=torch.int32)
+    st = _lib.stream(dev)
+    me = dist.get_rank(group) if len(ranks) > 1 else ranks[0]
+    k = len(ranks)
+    with torch.cuda.device(dev):
+        _lib.call("gptq_chol_begin", _lib.ptr(H), H.stride(0), C, float(percdamp), _lib.ptr(perm), _lib.ptr(info),
+                  _lib.ptr(ws), nbytes, st)
+        npan = -(-nblk // 4)
+        for j in range(npan):
+            p0, p1 = 4 * j, min(4 * j + 4, nblk)
+            owner = ranks[j % k]
+            if owner == me:
+                _lib.call("gptq_chol_panel", _lib.ptr(ws), C, p0, _lib.ptr(info), st)
+            if k > 1:
+                src = dist.get_global_rank(group, owner) if group is not None else owner
+                panel = A[p0 * 128:, p0 * 128:p1 * 128]
+                inv = [Linv[b * 128:(b + 1) * 128, b * 128:(b + 1) * 128] for b in range(p0, p1)]
+                if owner == me:
+                    buf = torch.cat([panel.reshape(-1)] + [x.reshape(-1) for x in inv])
+                else:
+                    buf = torch.empty(panel.numel() + sum(x.numel() for x in inv), device=dev, dtype=torch.float32)
+                _bcast(buf, src, sub)
+                if owner != me:
+                    panel.copy_(buf[:panel.numel()].view(panel.shape))
+                    off = panel.numel()
+                    for x in inv:
+                        x.copy_(buf[off:off + x.numel()].view(128, 128))
+                        off += x.numel()
+            for j2 in range(j + 1, npan):                       # the block columns of MY outer panels
+                if ranks[j2 % k] == me:
+                    _lib.call("gptq_chol_update", _lib.ptr(ws), C, p0, 4 * j2, min(4 * j2 + 4, nblk), st)
+        _lib.call("gptq_chol_end", _lib.ptr(H), H.stride(0), C, _lib.ptr(ws), st)
+    if k > 1:                                                   # a non-positive pivot on any rank is everybody's
+        flag = info.clone()
+        if flag.is_cuda and dist.get_backend(sub) != "nccl":
+            host = flag.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.MAX, group=sub)
+            flag.copy_(host)
+        else:
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=sub)
+        info = flag
+    return info
+
+
 def plan_rows(bundles: Sequence[Tuple[int, int]], world: int, align: int = 128) -> List[List[Tuple[int, int, int]]]:
     """bundles: (C, R) per distinct Hessian (R = stacked rows of the Linears that share it).  Returns, per bundle, the
     slabs (rank, row_a, row_b) that cover its rows.  A bundle's ranks all replicate its factorization chain (it depends
@@ -206,7 +300,35 @@ def fasterquant_sharded(solvers, bits: int, group=None, blocksize: int = 128, pe
     for st in lanes[1:]:
         st.wait_stream(cur)
     states = {}
-    order = sorted(mine, key=lambda t: -(C_of[t[0]] ** 3 + (t[2] - t[1]) * C_of[t[0]] ** 2))
+    # bundles whose rows are split over several ranks: the factorization is split over those ranks too (rfactor_sharded).
+    # new_group is collective: EVERY rank walks the bundles in the same order, members or not.
+    lib = gmod._lib.load()
+    shard = {}
+    for bi, slabs in enumerate(plan):
+        rk = [r for (r, _, _) in slabs]
+        ok = (SHARD_CHOL and len(rk) > 1 and C_of[bi] >= SHARD_CHOL_MIN_C and
+              lib.gptq_fasterquant_factor_form(C_of[bi], int(blocksize), int(groupsize), int(bool(static_groups))) == 1)
+        if ok:
+            shard[bi] = (rk, _subgroup(rk, group))
+    for (bi, a, e) in mine:
+        if bi not in shard:
+            continue
+        rk, sub = shard[bi]
+        b = bundles[bi]
+        L = b[0]
+        H = L._H
+        Cb = C_of[bi]
+        dead = torch.empty(Cb, device=dev, dtype=torch.int32)
+        perm = torch.empty(Cb, device=dev, dtype=torch.int32) if actorder else None
+        scratch = torch.empty(Cb, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            gmod._lib.call("gptq_solve_prepare", gmod._lib.ptr(H), H.stride(0), Cb, int(bool(actorder)), gmod._lib.ptr(dead),
+                           gmod._lib.ptr(perm), gmod._lib.ptr(scratch), gmod._lib.stream(dev))
+        info = rfactor_sharded(H, perm, percdamp, rk, group, sub)
+        W = _stacked_rows(b, a, e)
+        states[(bi, a, e)] = gmod._enqueue_rows(dev, W, H, L.quantizer, None, blocksize, percdamp, groupsize, actorder,
+                                                static_groups, factored=dict(dead=dead, perm=perm, info=info))
+    order = sorted([t for t in mine if t[0] not in shard], key=lambda t: -(C_of[t[0]] ** 3 + (t[2] - t[1]) * C_of[t[0]] ** 2))
     for k, (bi, a, e) in enumerate(order):
         b = bundles[bi]
         L = b[0]

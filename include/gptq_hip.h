@@ -129,6 +129,29 @@ int gptq_rfactor_upper(float* H, int ldh, int C, float percdamp, const int32_t* 
                        void* workspace, size_t workspace_bytes, gptq_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * gptq_rfactor_upper in pieces, for a factorization whose OUTER PANELS (512 columns = 4 blocks of 128) are spread over
+ * several GPUs.  The reference has no multi-GPU code; what these replace is still gptq.py:174-180.
+ * Every rank holds the same H (dead-column fix applied: gptq_solve_prepare) and the same workspace layout
+ * (gptq_hinv_workspace_bytes(C); C % 128 == 0): A = [C, C] floats at byte offset 0 (lower triangle: the reversed damped
+ * Hessian, then its Cholesky factor), Linv = [C, C] floats at byte offset C * C * 4 (only its diagonal 128-blocks).
+ *   gptq_chol_begin   builds A from H (damp = percdamp * mean(diag H); perm = act-order permutation or NULL).
+ *   gptq_chol_panel   factorizes outer panel p0 (first block, a multiple of 4): rows p0 * 128 ... C of the block columns
+ *                     [p0, p0 + 4) of A become the factor's, the diagonal blocks of Linv their inverses.  Its columns
+ *                     must already carry the updates of every earlier outer panel.  The owning rank then sends
+ *                     A[p0 * 128 :, p0 * 128 : (p0 + 4) * 128] and those four Linv blocks to the other ranks.
+ *   gptq_chol_update  A[:, block columns [tn0, tn1)] -= L[:, panel p0] L[those columns' rows, panel p0]^T (rank-512, lower
+ *                     tiles only), tn0 >= p0 + 4: each rank calls it for the block columns of the outer panels IT owns.
+ *   gptq_chol_end     H <- Rt above the diagonal blocks, U_kk inside them (as gptq_rfactor_upper leaves it), from the
+ *                     complete A / Linv.
+ * With one rank, begin; { panel(p0); update(p0, p0 + 4, C / 128) } for p0 = 0, 4, ...; end  is gptq_rfactor_upper.
+ * ------------------------------------------------------------------------- */
+int gptq_chol_begin(float* H, int ldh, int C, float percdamp, const int32_t* perm, int32_t* info, void* workspace,
+                    size_t workspace_bytes, gptq_stream_t stream);
+int gptq_chol_panel(void* workspace, int C, int p0, int32_t* info, gptq_stream_t stream);
+int gptq_chol_update(void* workspace, int C, int p0, int tn0, int tn1, gptq_stream_t stream);
+int gptq_chol_end(float* H, int ldh, int C, void* workspace, gptq_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * One lazy-batch block of the column loop -- replaces gptq.py:195-274 for a
  * single block [i1, i1+count) with the plain affine quantizer (gptq.py:251-264).
  * W [R, C] fp32 working weights: columns [i1, i1+count) are replaced by the
@@ -180,6 +203,20 @@ int gptq_fasterquant_rows(float* W, int ldw, float* H, int ldh, int R, int C, in
                           float* group_zero, int32_t* perm_out, uint8_t* codes, float* error_out,
                           float* row_loss, int32_t* info, void* workspace, size_t workspace_bytes,
                           gptq_stream_t stream);
+
+/* The head of the solve alone: dead-column fix of H's diagonal (gptq.py:143-145; dead_out [C] int32 flags) and, with
+ * actorder, perm_out = argsort(diag H, descending) (gptq.py:166).  scratch: [C] floats.  What a factorization spread over
+ * several GPUs (gptq_chol_*) needs before it starts. */
+int gptq_solve_prepare(float* H, int ldh, int C, int actorder, int32_t* dead_out, int32_t* perm_out, float* scratch,
+                       gptq_stream_t stream);
+/* gptq_fasterquant_rows for an H that ALREADY holds what gptq_rfactor_upper leaves (factor form only:
+ * gptq_fasterquant_factor_form must say 1), factorized elsewhere from the H that gptq_solve_prepare fixed, with that call's
+ * dead flags and (actorder) permutation: everything of gptq.py:126-305 but lines 143-144, 166 and 174-180. */
+int gptq_fasterquant_rows_factored(float* W, int ldw, float* H, int ldh, int R, int C, int bits, int sym, int blocksize,
+                                   int groupsize, int actorder, int static_groups, float* scale_io, float* zero_io,
+                                   int preset, float* group_scale, float* group_zero, const int32_t* dead_in,
+                                   const int32_t* perm_in, uint8_t* codes, float* error_out, float* row_loss,
+                                   int32_t* info, void* workspace, size_t workspace_bytes, gptq_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Bit packing -- replaces Quant3Linear.pack (quant.py:152-187) and the int4

@@ -359,3 +359,68 @@ def test_data_parallel_two_ranks_match_single_process(hip_device, tmp_path, kind
     ppl_dp = eval_ppl(other, test, hip_device)
     print(f"{kind}: perplexity single process {ppl_single:.4f}, 2-rank data-parallel {ppl_dp:.4f}")
     assert abs(ppl_dp - ppl_single) <= 5e-3 * ppl_single
+
+
+def _shard_chol_worker(rank, world, port, out_path):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)     # both ranks share cuda:0 on the 1-GPU box
+    try:
+        import gptq_amd
+        import gptq_amd.gptq as gmod
+        from gptq_amd import parallel as par
+        gmod.VERBOSE = False
+        par.SHARD_CHOL_MIN_C = 128
+        W, H = _shard_chol_case()
+        lin = torch.nn.Linear(W.shape[1], W.shape[0], bias=False, device="cuda:0", dtype=torch.float16)
+        lin.weight.data = W.half().cuda()
+        gp = gptq_amd.GPTQ(lin)
+        gp.quantizer = gptq_amd.Quantizer(); gp.quantizer.configure(4, perchannel=True, sym=False, mse=False)
+        gp.H = H.clone().cuda()
+        gp.nsamples = 1                                              # two ranks x the same H: the all-reduced mean IS H
+        (qw, stab, ztab), = par.fasterquant_sharded([gp], bits=4, actorder=True)
+        assert any(k for k in [1]) and len(par._SUBGROUPS) == 0      # the bundle spans both ranks: the default group
+        if rank == 0:
+            torch.save({"w": lin.weight.data.cpu(), "error": gp.error, "perm": gp.perm.cpu(), "qw": qw.cpu()}, out_path)
+    finally:
+        dist.destroy_process_group()
+
+
+def _shard_chol_case():
+    gen = torch.Generator().manual_seed(11)
+    R, C = 512, 1536                                                 # 12 blocks = 3 outer panels: rank 0 owns 0 and 2
+    W = (torch.randn(R, C, generator=gen) * 0.02).half().float()
+    X = torch.randn(2 * C, C, generator=gen) * (1 + torch.arange(C) % 7)
+    return W, ((X.t() @ X) * (2.0 / X.shape[0])).float()
+
+
+@pytest.mark.timeout(300)
+def test_factorization_sharded_over_two_ranks_changes_nothing(hip_device, tmp_path):
+    """gptq_amd.parallel.rfactor_sharded at world 2 (both ranks on the test card, gloo staging): outer panels 0 and 2 are
+    factorized by rank 0, panel 1 by rank 1, each panel broadcast once, each rank updating its own block columns.  The
+    factor is bit-identical to the single-rank one (same kernels, same k order), so the sharded solve must return the very
+    weights, permutation and error of a single-process fasterquant on the same H."""
+    import socket
+    import torch.multiprocessing as mp
+    import gptq_amd
+    import gptq_amd.gptq as gmod
+    gmod.VERBOSE = False
+    W, H = _shard_chol_case()
+    lin = torch.nn.Linear(W.shape[1], W.shape[0], bias=False, device=hip_device, dtype=torch.float16)
+    lin.weight.data = W.half().to(hip_device)
+    gp = gptq_amd.GPTQ(lin)
+    gp.quantizer = gptq_amd.Quantizer(); gp.quantizer.configure(4, perchannel=True, sym=False, mse=False)
+    gp.H = H.clone().to(hip_device)
+    gp.nsamples = 2
+    gp.fasterquant(blocksize=128, percdamp=0.01, actorder=True)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "shardchol.pt")
+    mp.spawn(_shard_chol_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=True)
+    assert torch.equal(got["perm"], gp.perm.cpu())
+    assert torch.equal(got["w"], lin.weight.data.cpu())
+    assert abs(got["error"] - gp.error) <= 1e-6 * abs(gp.error)
+    assert torch.equal(got["qw"], gptq_amd.pack_codes(gp.codes, 4).cpu())

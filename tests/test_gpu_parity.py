@@ -285,6 +285,27 @@ def test_super_block_kernel_bit_identical_to_per_block_path(G, R, C, kw, monkeyp
         assert out["0"][4] == out[lanes][4], (lanes, out["0"][4], out[lanes][4])
 
 
+@pytest.mark.parametrize("C,actorder", [(640, False), (1408, True), (2048, False)])
+def test_chain_in_pieces_is_bit_identical_to_rfactor_upper(C, actorder):
+    """gptq_chol_begin / _panel / _update / _end (the factorization as gptq_amd.parallel.rfactor_sharded drives it, here with
+    ONE rank owning every outer panel) against gptq_rfactor_upper on the same H: same kernels, same k order -- the same
+    bits, so a factorization spread over several GPUs changes no code."""
+    from gptq_amd import _lib
+    from gptq_amd import parallel as par
+    gen = torch.Generator().manual_seed(C)
+    X = torch.randn(3 * C, C, generator=gen) * (1 + torch.arange(C) % 7)
+    H = ((X.t() @ X) * (2 / (3 * C))).float()
+    perm = torch.argsort(torch.diag(H), descending=True).to(torch.int32) if actorder else None
+    ref, info = _hinv_gpu(H, 0.01, perm, entry="gptq_rfactor_upper")
+    assert info == 0
+    Hd = H.clone().cuda()
+    got_info = par.rfactor_sharded(Hd, perm.cuda() if perm is not None else None, 0.01, [0])
+    assert int(got_info.item()) == 0
+    blk = torch.arange(C) // 128
+    valid = blk[:, None] <= blk[None, :]                   # Rt above the diagonal blocks, U_kk inside them
+    assert torch.equal(Hd.cpu()[valid], ref[valid])
+
+
 def test_hinv_not_positive_definite_raises(G, hip_device):
     C = 256
     H = -torch.eye(C)
