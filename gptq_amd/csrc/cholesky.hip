@@ -200,14 +200,15 @@ __device__ int potrf_ablate;
 #else
 #define POTRF_STAMP(i) do { } while (0)
 #endif
-__global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__ A, float* __restrict__ Linv,
-                                                             int Cp, int kb, int32_t* __restrict__ info) {
+// (WT: the block's inverse leaves with write-through `sc1` stores -- chol_panel_kernel hands it to other workgroups of the
+//  same launch behind a flag)
+template <bool WT>
+__device__ __forceinline__ void potrf_inv_diag_block(float* dsm, float* __restrict__ A, float* __restrict__ Linv, int Cp,
+                                                     int kb, int32_t* __restrict__ info) {
   // ONE 128 x 129 image (66 KB) serves the block, its factor and its inverse: a sub-block's inverse replaces it as
   // soon as it is final.  The footprint matters: the kernel is a single workgroup on the critical path and must find
   // a compute unit with that much free LDS beside the big low-priority updates of the helper stream.
-  critical_path_priority();
   constexpr int LD = NB + 1;            // 129: row-strided accesses (lane = row) are conflict-free
-  extern __shared__ __attribute__((aligned(16))) float dsm[];
   float* S = dsm;                       // [128][129]  A_kk (full, mirrored) -> L off-diagonal blocks -> L_kk^-1
   float* Tt = S + 64;                   // [64][LD]    level-2 intermediate, in the dead quadrant S[0:64, 64:128]
   float* Ld = S + NB * LD;              // [32][33]    factor of the current diagonal 32 x 32 sub-block (+ 32 scratch floats)
@@ -371,11 +372,21 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
 #pragma unroll 8
   for (int idx = tid; idx < NB * NB; idx += 512) {
     const int i = idx >> 7, k = idx & 127;
-    Xk[(long)i * Cp + k] = (k <= i) ? S[i * LD + k] : 0.f;
+    const float x = (k <= i) ? S[i * LD + k] : 0.f;
+    if (WT) __hip_atomic_store(Xk + (long)i * Cp + k, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else Xk[(long)i * Cp + k] = x;
   }
   POTRF_STAMP(16);
 }
-constexpr size_t POTRF_LDS = sizeof(float) * (NB * (NB + 1) + 32 * 33 + 32 + 32 + 4);
+constexpr int POTRF_LDS_FLOATS = NB * (NB + 1) + 32 * 33 + 32 + 32 + 4;
+constexpr size_t POTRF_LDS = sizeof(float) * POTRF_LDS_FLOATS;
+
+__global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__ A, float* __restrict__ Linv,
+                                                             int Cp, int kb, int32_t* __restrict__ info) {
+  critical_path_priority();
+  extern __shared__ __attribute__((aligned(16))) float dsm[];
+  potrf_inv_diag_block<false>(dsm, A, Linv, Cp, kb, info);
+}
 
 
 // Panel:  P <- P * inv(L_kk)^T  for the block column kb below the diagonal (rows (kb+1)*128 ...), IN PLACE.
@@ -488,6 +499,165 @@ static inline int syrk_tiles(int nblk, int tn0, int tn1) {       // sum_{tn in [
   return n <= 0 ? 0 : n * nblk - (tn0 + tn1 - 1) * n / 2;
 }
 
+// ---------------------------------------------------------------------------------------------
+// ONE launch per outer panel [p0, p1) of the factorization (round 3) instead of three per 128-column step: the diagonal
+// chain, the panel solves of all rows below and the rank-128 updates inside the outer panel are ROLES of one resident
+// grid, handed from role to role through flags in device memory.
+//   workgroup 0 ("chain"): for kb = p0 .. p1 - 1: wait until the two 64-row slabs of row block kb carry the updates of
+//     step kb - 1, factorize + invert the diagonal block (potrf_inv_diag_block), publish D = step kb.
+//   workgroup 1 + j ("slabs" j, j + nwg, ...; slab s = 64 rows: row block p0 + 1 + s / 2, half s & 1): for every step kb
+//     above its rows: wait for D, solve its 64 x 128 piece of the panel in place (panel_kernel's product), publish it if
+//     its rows lie inside the outer panel (their pieces are the B operands of everybody's updates), then apply the
+//     rank-128 update to its rows of the block columns kb + 1 .. p1 - 1 (syrk_kernel's 64 x 64 tiles) as soon as the
+//     slabs of those block columns have published, and publish "done" (the chain's go-ahead for its next block).
+// What this buys is look-ahead without a stream hand-off per step: the chain waits for ONE row block's panel solve and
+// diagonal-tile update (two of the up to 170 slabs), the other slabs work underneath the next diagonal block.
+// Same device functions, same ascending k order as the separate launches: the factor is bit-identical.
+// Hand-offs (MI355X_MICROARCH.md, inter-workgroup visibility): handed-off bytes leave with write-through `sc1` stores,
+// every storing wave drains vmcnt, workgroup barrier, one relaxed agent-scope flag store; the consumer polls relaxed
+// from one lane, then ONE agent-scope acquire + vmcnt(0) + workgroup barrier, then plain loads.  Flags are monotonic
+// (8 * launch index + step + 1; zeroed once per factorization), nobody ever waits for a slab below the outer panel, and
+// every wait is bounded: a workgroup that gives up raises `abort` (every poller sees it) and reports info = -9.
+// Residency: a waited-for workgroup (chain, slabs of the outer panel: the 7 lowest block indices) never waits for a
+// workgroup above itself in dispatch order, and the grid is capped well under what the idle chip holds.
+// ---------------------------------------------------------------------------------------------
+struct PanelArgs {
+  float* A;
+  float* Linv;
+  int32_t* info;
+  int* flags;        // [0] abort, [1] D, [4 + 2 s] panel piece of slab s stored, [5 + 2 s] slab s done with the step
+  int Cp, nblk, p0, p1, base, nwg;
+};
+constexpr int PANEL_FLAG_SLAB0 = 4;
+constexpr int PANEL_SPIN_LIMIT = 1 << 21;                // polls of ~1 us each
+
+// all live threads of the workgroup; true = go on, false = somebody gave up
+__device__ __forceinline__ bool panel_wait(const PanelArgs& a, const int* f0, const int* f1, int val, int* lds_word) {
+  if (threadIdx.x == 0) {
+    int it = 0, ok = 1;
+    while (__hip_atomic_load(f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < val ||
+           __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < val) {
+      __builtin_amdgcn_s_sleep(2);
+      if ((++it & 31) == 0) {
+        if (__hip_atomic_load(a.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
+        if (it > PANEL_SPIN_LIMIT) {
+          __hip_atomic_store(a.flags, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (a.info) atomicCAS(a.info, 0, -9);
+          ok = 0;
+          break;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    *lds_word = ok;
+  }
+  __syncthreads();
+  const int ok = *lds_word;
+  __syncthreads();                                        // (the word may be rewritten by the next wait)
+  return ok != 0;
+}
+// all live threads of the workgroup, after their `sc1` stores
+__device__ __forceinline__ void panel_publish(int* flag, int val) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(512) void chol_panel_kernel(PanelArgs a) {
+  critical_path_priority();
+  extern __shared__ __attribute__((aligned(16))) float dsm[];
+  int* lds_word = reinterpret_cast<int*>(dsm + POTRF_LDS_FLOATS);
+  const int Cp = a.Cp;
+  if (blockIdx.x == 0) {                                    // ---- the chain ----
+    for (int kb = a.p0; kb < a.p1; ++kb) {
+      if (kb > a.p0) {
+        const int s0 = 2 * (kb - a.p0 - 1);
+        if (!panel_wait(a, a.flags + PANEL_FLAG_SLAB0 + 2 * s0 + 1, a.flags + PANEL_FLAG_SLAB0 + 2 * s0 + 3,
+                        a.base + (kb - 1 - a.p0) + 1, lds_word))
+          return;
+      }
+      potrf_inv_diag_block<true>(dsm, a.A, a.Linv, Cp, kb, a.info);
+      panel_publish(a.flags + 1, a.base + (kb - a.p0) + 1);
+    }
+    return;
+  }
+  if (threadIdx.x >= GEMM_THREADS) return;                  // ---- slabs: four waves (the tile code's geometry) ----
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nslab = 2 * (a.nblk - a.p0 - 1);
+  for (int kb = a.p0; kb < a.p1; ++kb) {
+    const int val = a.base + (kb - a.p0) + 1;
+    bool have_d = false;
+    for (int s = blockIdx.x - 1; s < nslab; s += a.nwg) {
+      const int tm = a.p0 + 1 + (s >> 1), sm = s & 1;
+      if (tm <= kb) continue;                               // this row block is (or was) the chain's
+      if (!have_d) {
+        if (!panel_wait(a, a.flags + 1, a.flags + 1, val, lds_word)) return;
+        have_d = true;
+      }
+      const bool inside = tm < a.p1;                        // rows of the outer panel: their results are handed on
+      float* P = a.A + ((long)tm * NB + 64 * sm) * Cp + (long)kb * NB;
+      {                                                     // panel piece: P <- P inv(L_kk)^T (panel_kernel)
+        const float* D = a.Linv + (long)kb * NB * Cp + (long)kb * NB;
+        Operand<float> pa{P, Cp, 1, 64, true};
+        Operand<float> b0{D, Cp, 1, 64, true};
+        Operand<float> b1{D + 64L * Cp, Cp, 1, 64, true};
+        f32x16 acc0, acc1;
+        gemm_acc64x2<float, float, true, true>(pa, b0, b1, 0, 64, NB, dsm, acc0, acc1);
+        Epilogue e0{P, Cp, 1, EPI_STORE, TRI_ALL, 0.f, 0.f}, e1{P + 64, Cp, 1, EPI_STORE, TRI_ALL, 0.f, 0.f};
+        e0.wt = e1.wt = inside;
+        tile_epilogue64(acc0, e0, 64, 64, wave >> 1, wave & 1, lane);
+        tile_epilogue64(acc1, e1, 64, 64, wave >> 1, wave & 1, lane);
+      }
+      if (inside) panel_publish(a.flags + PANEL_FLAG_SLAB0 + 2 * s, val);
+      else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }   // (own P is an operand next)
+      const int c_last = min(a.p1 - 1, tm);
+      for (int c = kb + 1; c <= c_last; ++c) {              // A[slab, c] -= P_slab P_c^T (syrk_kernel's tiles)
+        const int sc = 2 * (c - a.p0 - 1);                  // the slabs of row block c
+        if (c < tm || sm == 1) {                            // (a diagonal block's upper slab needs only its own piece)
+          const int* f0 = a.flags + PANEL_FLAG_SLAB0 + 2 * sc;
+          const int* f1 = (c == tm) ? f0 : f0 + 2;          // (own piece: published above)
+          if (!panel_wait(a, f0, f1, val, lds_word)) return;
+        }
+        for (int sn = 0; sn < 2; ++sn) {
+          if (c == tm && sn > sm) continue;                 // strictly upper quarter of a diagonal block
+          Operand<float> ua{P, Cp, 1, 64, true};
+          Operand<float> ub{a.A + ((long)c * NB + 64 * sn) * Cp + (long)kb * NB, Cp, 1, 64, true};
+          Epilogue ep{a.A + ((long)tm * NB + 64 * sm) * Cp + (long)c * NB + 64 * sn, Cp, 1, EPI_SUB,
+                      (c == tm && sn == sm) ? TRI_LOWER : TRI_ALL, 0.f, 0.f};
+          ep.wt = inside;
+          gemm_tile64<float, float, true, true>(ua, ub, 0, NB, dsm, ep);
+        }
+      }
+      if (inside) panel_publish(a.flags + PANEL_FLAG_SLAB0 + 2 * s + 1, val);
+    }
+  }
+}
+constexpr size_t PANEL_LDS = POTRF_LDS + 16;
+static_assert(PANEL_LDS >= sizeof(float) * GEMM64X2_LDS_FLOATS, "the slab role's tile code needs its LDS too");
+static inline int panel_slab_wgs(int nblk, int p0) {
+  static const int cap = [] { const char* e = getenv("GPTQ_CHOL_WGS"); return e ? atoi(e) : 160; }();
+  const int nslab = 2 * (nblk - p0 - 1);
+  return std::max(std::min(nslab, std::max(cap, 8)), 0);
+}
+static inline int chol_persist() {
+  static const int v = [] { const char* e = getenv("GPTQ_CHOL_PERSIST"); return e ? atoi(e) : 1; }();
+  return v;
+}
+static int launch_panel(float* A, float* Linv, int Cp, int nblk, int p0, int p1, int32_t* info, int* flags,
+                        hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_panel_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS));
+    attr_set = true;
+  }
+  PanelArgs pa{A, Linv, info, flags, Cp, nblk, p0, p1, 8 * (p0 / CSUPER), panel_slab_wgs(nblk, p0)};
+  chol_panel_kernel<<<1 + pa.nwg, 512, PANEL_LDS, s>>>(pa);
+  return GPTQ_OK;
+}
+static inline size_t panel_flag_ints(int nblk) { return PANEL_FLAG_SLAB0 + 4 * (size_t)nblk + 64; }
+
 // Recursive-doubling inverse, level with segment size s (in 128-blocks).  For every pair
 // (A = blocks [2ps, 2ps+s), Cc = blocks [2ps+s, 2ps+2s) clipped) the off-diagonal block of the
 // inverse is X = -Cc^-1 * B * A^-1 with B = L[Cc, A].
@@ -578,6 +748,7 @@ extern "C" size_t gptq_hinv_workspace_bytes(int C) {
   cv.take<float>(Cp * Cp);   // Abar / L
   cv.take<float>(Cp * Cp);   // Linv (+ T^T in its upper triangle)
   cv.take<float>(64);        // damp
+  cv.take<int>(panel_flag_ints((int)(Cp / NB)));   // hand-off flags of chol_panel_kernel
   return cv.used();
 }
 
@@ -593,8 +764,11 @@ static int factor_chain(float* H, int ldh, int C, float percdamp, const int32_t*
   float* A = cv.take<float>((size_t)Cp * Cp);
   float* Linv = cv.take<float>((size_t)Cp * Cp);
   float* damp = cv.take<float>(64);
+  int* flags = cv.take<int>(panel_flag_ints(nblk));
 
   diag_mean_kernel<<<1, 256, 0, s>>>(H, ldh, C, percdamp, damp, info);
+  const bool persist = chol_persist() != 0;
+  if (persist) GPTQ_CHECK_HIP(hipMemsetAsync(flags, 0, sizeof(int) * panel_flag_ints(nblk), s));
   const bool lds_gather = perm && C % 4 == 0 && ldh % 4 == 0 && C <= 36864 && reinterpret_cast<uintptr_t>(H) % 16 == 0;
   if (lds_gather) {
     if (int rc = gptq_symmetrize(H, ldh, C, stream)) return rc;   // (H is consumed: its lower triangle is free)
@@ -625,6 +799,8 @@ static int factor_chain(float* H, int ldh, int C, float percdamp, const int32_t*
       }
       // ... and ONE launch for the rows below it
       if (p1 < nblk) panel_super_kernel<<<2 * (nblk - p1), GEMM_THREADS, 0, s>>>(A, Linv, Cp, p0, p1 - p0, p1);
+    } else if (persist) {
+      if (int rc = launch_panel(A, Linv, Cp, nblk, p0, p1, info, flags, s)) return rc;
     } else {
     for (int kb = p0; kb < p1; ++kb) {
       potrf_inv_diag_kernel<<<1, 512, POTRF_LDS, s>>>(A, Linv, Cp, kb, info);
@@ -700,13 +876,14 @@ extern "C" int gptq_diag_potrf_stamps(unsigned long long* out17) {
 // Workspace: gptq_hinv_workspace_bytes(C); A = [Cp, Cp] floats at offset 0, the diagonal blocks' inverses in Linv =
 // [Cp, Cp] floats at offset Cp * Cp * 4 (Cp = C rounded up to 128: both offsets are 256-byte aligned).
 // ---------------------------------------------------------------------------------------------
-static int chol_ws(void* workspace, int C, float** A, float** Linv, float** damp) {
+static int chol_ws(void* workspace, int C, float** A, float** Linv, float** damp, int** flags = nullptr) {
   GPTQ_CHECK_ARG(workspace && C > 0 && C % NB == 0, "gptq_chol_*: C must be a positive multiple of 128");
   GPTQ_CHECK_ARG(reinterpret_cast<uintptr_t>(workspace) % 256 == 0, "gptq_chol_*: workspace must be 256-byte aligned");
   Carver cv(workspace);
   *A = cv.take<float>((size_t)C * C);
   *Linv = cv.take<float>((size_t)C * C);
   *damp = cv.take<float>(64);
+  if (flags) *flags = cv.take<int>(panel_flag_ints(C / NB));
   return GPTQ_OK;
 }
 
@@ -715,8 +892,10 @@ extern "C" int gptq_chol_begin(float* H, int ldh, int C, float percdamp, const i
   GPTQ_CHECK_ARG(H && ldh >= C, "gptq_chol_begin: bad arguments");
   GPTQ_CHECK_ARG(workspace_bytes >= gptq_hinv_workspace_bytes(C), "gptq_chol_begin: workspace too small");
   float *A, *Linv, *damp;
-  if (int rc = chol_ws(workspace, C, &A, &Linv, &damp)) return rc;
+  int* flags;
+  if (int rc = chol_ws(workspace, C, &A, &Linv, &damp, &flags)) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  GPTQ_CHECK_HIP(hipMemsetAsync(flags, 0, sizeof(int) * panel_flag_ints(C / NB), s));
   diag_mean_kernel<<<1, 256, 0, s>>>(H, ldh, C, percdamp, damp, info);
   build_abar_kernel<<<dim3(cdiv(C, 256), C), 256, 0, s>>>(H, ldh, C, C, perm, damp, A);
   GPTQ_CHECK_LAUNCH("gptq_chol_begin");
@@ -725,13 +904,19 @@ extern "C" int gptq_chol_begin(float* H, int ldh, int C, float percdamp, const i
 
 extern "C" int gptq_chol_panel(void* workspace, int C, int p0, int32_t* info, gptq_stream_t stream) {
   float *A, *Linv, *damp;
-  if (int rc = chol_ws(workspace, C, &A, &Linv, &damp)) return rc;
+  int* flags;
+  if (int rc = chol_ws(workspace, C, &A, &Linv, &damp, &flags)) return rc;
   const int nblk = C / NB;
   GPTQ_CHECK_ARG(p0 >= 0 && p0 < nblk && p0 % CSUPER == 0, "gptq_chol_panel: p0 must be the first block of an outer panel");
   hipStream_t s = static_cast<hipStream_t>(stream);
   GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_inv_diag_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_LDS));
   const int p1 = std::min(p0 + CSUPER, nblk);
+  if (chol_persist()) {
+    if (int rc = launch_panel(A, Linv, C, nblk, p0, p1, info, flags, s)) return rc;
+    GPTQ_CHECK_LAUNCH("gptq_chol_panel");
+    return GPTQ_OK;
+  }
   for (int kb = p0; kb < p1; ++kb) {
     potrf_inv_diag_kernel<<<1, 512, POTRF_LDS, s>>>(A, Linv, C, kb, info);
     const int nrem = nblk - kb - 1;

@@ -103,7 +103,11 @@ __device__ __forceinline__ void tile_finish64(const f32x16& acc, const float (&o
     else if (ep.mode == EPI_STORE_NEG) out = -v;
     else if (ep.mode == EPI_SUB) out = old[e] - v;
     else out = ep.alpha * old[e] + ep.beta * v;
-    if (keep) ep.C[(long)row * ep.rs + (long)col * ep.cs] = out;
+    if (keep) {
+      float* dst = ep.C + (long)row * ep.rs + (long)col * ep.cs;
+      if (ep.wt) __hip_atomic_store(dst, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else *dst = out;
+    }
   }
   G64_STAMP(3);
 }

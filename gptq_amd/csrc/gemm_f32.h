@@ -146,6 +146,8 @@ struct Epilogue {
   int mode;
   int tri;
   float alpha, beta;   // EPI_AXPBY: C = alpha * C + beta * acc
+  bool wt = false;     // write-through (`sc1`) stores: the tile is handed to another workgroup of the SAME launch behind
+                       // a flag (chol_panel_kernel); honoured by the 64 x 64 tile's epilogue only
 };
 
 // The old values of a read-modify-write epilogue, loaded BEFORE the product (the tile belongs to this workgroup alone):
