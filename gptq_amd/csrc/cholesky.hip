@@ -202,9 +202,31 @@ __device__ int potrf_ablate;
 #endif
 // (WT: the block's inverse leaves with write-through `sc1` stores -- chol_panel_kernel hands it to other workgroups of the
 //  same launch behind a flag)
+// The block's lower triangle from A into the 128 x 129 image S, mirrored (diagonal tiles are kept full): coalesced, ALL 32
+// loads of a thread in flight before the first one is used (the plain loop took 21 k of the kernel's 106 k cycles: one L2
+// round trip per iteration); the transposed store has stride 129: conflict-free.  The caller passes a barrier next.
+__device__ __forceinline__ void potrf_load_block(float* S, const float* __restrict__ Ak, int Cp, const int tid) {
+  constexpr int LD = NB + 1;
+  float v[NB * NB / 512];
+#pragma unroll
+  for (int j = 0; j < NB * NB / 512; ++j) {
+    const int idx = tid + 512 * j, i = idx >> 7, k = idx & 127;
+    v[j] = (k <= i) ? Ak[(long)i * Cp + k] : 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < NB * NB / 512; ++j) {
+    const int idx = tid + 512 * j, i = idx >> 7, k = idx & 127;
+    if (k <= i) {
+      S[i * LD + k] = v[j];
+      S[k * LD + i] = v[j];
+    }
+  }
+}
+// (WT: the block's inverse leaves with write-through `sc1` stores -- chol_panel_kernel hands it to other workgroups of the
+//  same launch behind a flag.)  S = dsm holds the mirrored block; no barrier needed in between.
 template <bool WT>
 __device__ __forceinline__ void potrf_inv_diag_block(float* dsm, float* __restrict__ A, float* __restrict__ Linv, int Cp,
-                                                     int kb, int32_t* __restrict__ info) {
+                                                     int kb, int32_t* __restrict__ info, const int tid) {
   // ONE 128 x 129 image (66 KB) serves the block, its factor and its inverse: a sub-block's inverse replaces it as
   // soon as it is final.  The footprint matters: the kernel is a single workgroup on the critical path and must find
   // a compute unit with that much free LDS beside the big low-priority updates of the helper stream.
@@ -214,30 +236,10 @@ __device__ __forceinline__ void potrf_inv_diag_block(float* dsm, float* __restri
   float* Ld = S + NB * LD;              // [32][33]    factor of the current diagonal 32 x 32 sub-block (+ 32 scratch floats)
   volatile float* invs = Ld + 32 * 33 + 32;                       // [32] 1 / l_jj of the current sub-block (wave 0 -> wave 1)
   volatile int* step = reinterpret_cast<volatile int*>(Ld + 32 * 33 + 64);   // columns published so far (monotonic)
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* Ak = A + (long)kb * NB * Cp + (long)kb * NB;
 
-  POTRF_STAMP(0);
-  {
-    // the lower triangle, coalesced, ALL 32 loads of a thread in flight before the first one is used (the plain loop
-    // took 21 k of the kernel's 106 k cycles: one L2 round trip per iteration), mirrored while it is stored (diagonal
-    // tiles are kept full; the transposed store has stride 129: conflict-free)
-    float v[NB * NB / 512];
-#pragma unroll
-    for (int j = 0; j < NB * NB / 512; ++j) {
-      const int idx = tid + 512 * j, i = idx >> 7, k = idx & 127;
-      v[j] = (k <= i) ? Ak[(long)i * Cp + k] : 0.f;
-    }
-#pragma unroll
-    for (int j = 0; j < NB * NB / 512; ++j) {
-      const int idx = tid + 512 * j, i = idx >> 7, k = idx & 127;
-      if (k <= i) {
-        S[i * LD + k] = v[j];
-        S[k * LD + i] = v[j];
-      }
-    }
-  }
   if (tid == 0) *step = 0;
   __syncthreads();
   POTRF_STAMP(1);
@@ -385,7 +387,9 @@ __global__ __launch_bounds__(512) void potrf_inv_diag_kernel(float* __restrict__
                                                              int Cp, int kb, int32_t* __restrict__ info) {
   critical_path_priority();
   extern __shared__ __attribute__((aligned(16))) float dsm[];
-  potrf_inv_diag_block<false>(dsm, A, Linv, Cp, kb, info);
+  POTRF_STAMP(0);
+  potrf_load_block(dsm, A + (long)kb * NB * Cp + (long)kb * NB, Cp, threadIdx.x);
+  potrf_inv_diag_block<false>(dsm, A, Linv, Cp, kb, info, threadIdx.x);
 }
 
 
@@ -529,6 +533,13 @@ struct PanelArgs {
   int Cp, nblk, p0, p1, base, nwg;
 };
 constexpr int PANEL_FLAG_SLAB0 = 4;
+#ifdef GPTQ_DIAG   // s_memtime stamps of the chain (0..15) and of slabs 0 / 1 (16..47 / 48..79) in the launch p0 == panel_stamp_p0
+__device__ unsigned long long panel_stamps[96];
+__device__ int panel_stamp_p0;
+#define PANEL_STAMP(i) do { if (threadIdx.x == 0 && a.p0 == panel_stamp_p0) panel_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PANEL_STAMP(i) do { } while (0)
+#endif
 constexpr int PANEL_SPIN_LIMIT = 1 << 21;                // polls of ~1 us each
 
 // all live threads of the workgroup; true = go on, false = somebody gave up
@@ -570,15 +581,124 @@ __global__ __launch_bounds__(512) void chol_panel_kernel(PanelArgs a) {
   int* lds_word = reinterpret_cast<int*>(dsm + POTRF_LDS_FLOATS);
   const int Cp = a.Cp;
   if (blockIdx.x == 0) {                                    // ---- the chain ----
+    constexpr int LD = NB + 1;
+    float* S = dsm;
+#pragma unroll 1
     for (int kb = a.p0; kb < a.p1; ++kb) {
-      if (kb > a.p0) {
-        const int s0 = 2 * (kb - a.p0 - 1);
-        if (!panel_wait(a, a.flags + PANEL_FLAG_SLAB0 + 2 * s0 + 1, a.flags + PANEL_FLAG_SLAB0 + 2 * s0 + 3,
-                        a.base + (kb - 1 - a.p0) + 1, lds_word))
-          return;
+      // (the thread index is laundered once per step: left alone hipcc hoists the diagonal block's per-lane LDS addresses
+      //  out of this loop and spills them -- 270 registers, reloaded inside the 32-step chains)
+      int tid = threadIdx.x;
+      asm volatile("" : "+v"(tid));
+      const int lane = tid & 63, r = lane & 31, h = lane >> 5;
+      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+      PANEL_STAMP(4 * (kb - a.p0));
+      if (kb == a.p0) {
+        PANEL_STAMP(1);
+        potrf_load_block(dsm, a.A + (long)kb * NB * Cp + (long)kb * NB, Cp, tid);
+      } else {
+        // Look-ahead inside the chain: S still holds X = inv(L_(kb-1)), so this workgroup solves ITS next panel block
+        // P = A[kb, kb-1] X^T and updates ITS next diagonal tile D = A[kb, kb] - P P^T itself -- no hand-off on the
+        // critical path.  The slabs of row block kb brought both blocks up to step kb - 2 (their "done" flags).
+        if (kb > a.p0 + 1) {
+          const int s0 = 2 * (kb - a.p0 - 1);
+          if (!panel_wait(a, a.flags + PANEL_FLAG_SLAB0 + 2 * s0 + 1, a.flags + PANEL_FLAG_SLAB0 + 2 * s0 + 3,
+                          a.base + (kb - 2 - a.p0) + 1, lds_word))
+            return;
+        }
+        PANEL_STAMP(4 * (kb - a.p0) + 1);
+        float* Pg = a.A + (long)kb * NB * Cp + (long)(kb - 1) * NB;     // block (kb, kb-1), in place
+        const float* Dg = a.A + (long)kb * NB * Cp + (long)kb * NB;     // tile (kb, kb), lower triangle
+        // (a) P: wave w forms the 32 x 32 tiles (I, N) of rows I = w >> 1 with N in {0, 3} or {1, 2} (X is lower
+        //     triangular: tile (I, N) runs over the k tiles 0 .. N -- 80 MFMAs per wave either way).  A's fragments come
+        //     straight from L2: lane (r, h) needs A[32 I + r][2 kk + h], i.e. two of every four consecutive floats.
+        const int I = wave >> 1;
+        const int N0 = (wave & 1) ? 1 : 0, N1 = (wave & 1) ? 2 : 3;
+        float4 af[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) af[j] = *reinterpret_cast<const float4*>(Pg + (long)(32 * I + r) * Cp + 4 * j);
+        // the old values of the diagonal tile's lower 32 x 32 tiles: tile t of 10 -> (TI, TK), wave w takes t = w and, for
+        // w < 2, t = 8 + w
+        auto tile_ik = [](int t, int& ti, int& tk) { ti = 0; while (t > ti) { t -= ti + 1; ++ti; } tk = t; };
+        int TI0, TK0, TI1 = 0, TK1 = 0;
+        tile_ik(wave, TI0, TK0);
+        const bool two = wave < 2;
+        if (two) tile_ik(8 + wave, TI1, TK1);
+        float old0[16], old1[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+          old0[e] = Dg[(long)(32 * TI0 + row) * Cp + 32 * TK0 + r];
+          old1[e] = two ? Dg[(long)(32 * TI1 + row) * Cp + 32 * TK1 + r] : 0.f;
+        }
+        f32x16 pa0, pa1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { pa0[e] = 0.f; pa1[e] = 0.f; }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          if (kt <= N1) {
+            const float* X1 = S + (32 * N1 + r) * LD + 32 * kt + h;
+            const float* X0 = S + (32 * N0 + r) * LD + 32 * kt + h;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+              const float4 v = af[8 * kt + (kk >> 1)];
+              const float av = (kk & 1) ? (h ? v.w : v.z) : (h ? v.y : v.x);
+              if (kt <= N0) pa0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, X0[2 * kk], pa0, 0, 0, 0);
+              pa1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, X1[2 * kk], pa1, 0, 0, 0);
+            }
+          }
+        }
+        __syncthreads();                                       // every wave is done with X
+        // (b) P into S (the operand image of the update) and, write-through, in place into A (the slabs' B operand)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = 32 * I + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const float v0 = pa0[e], v1 = pa1[e];                  // (scalars first: a vector ELEMENT handed to a builtin that
+                                                               //  bit-casts it reads element 0 -- hipcc, ROCm 7.2)
+          S[row * LD + 32 * N0 + r] = v0;
+          S[row * LD + 32 * N1 + r] = v1;
+          __hip_atomic_store(Pg + (long)row * Cp + 32 * N0 + r, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(Pg + (long)row * Cp + 32 * N1 + r, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        {                                                      // = the panel pieces of the two slabs of row block kb
+          const int sk = 2 * (kb - a.p0 - 1), pv = a.base + (kb - 1 - a.p0) + 1;
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();                                     // (also: P is complete in S)
+          if (tid == 0) {
+            __hip_atomic_store(a.flags + PANEL_FLAG_SLAB0 + 2 * sk, pv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.flags + PANEL_FLAG_SLAB0 + 2 * sk + 2, pv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        // (c) D = old - P P^T on the lower tiles: from zero over k = 0 .. 127 ascending, then old - acc (syrk_kernel's EPI_SUB)
+        f32x16 d0, d1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { d0[e] = 0.f; d1[e] = 0.f; }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          lds_mfma32(d0, S + 32 * TI0 * LD + 32 * kt, LD, S + 32 * TK0 * LD + 32 * kt, LD, 1.f, lane);
+          if (two) lds_mfma32(d1, S + 32 * TI1 * LD + 32 * kt, LD, S + 32 * TK1 * LD + 32 * kt, LD, 1.f, lane);
+        }
+        __syncthreads();                                       // every wave is done with P
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {                         // the mirrored block, as the load phase leaves it
+          const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+          const float v0 = old0[e] - d0[e];
+          if (TI0 > TK0 || row >= r) {
+            S[(32 * TI0 + row) * LD + 32 * TK0 + r] = v0;
+            S[(32 * TK0 + r) * LD + 32 * TI0 + row] = v0;
+          }
+          if (two) {
+            const float v1 = old1[e] - d1[e];
+            if (TI1 > TK1 || row >= r) {
+              S[(32 * TI1 + row) * LD + 32 * TK1 + r] = v1;
+              S[(32 * TK1 + r) * LD + 32 * TI1 + row] = v1;
+            }
+          }
+        }
       }
-      potrf_inv_diag_block<true>(dsm, a.A, a.Linv, Cp, kb, a.info);
+      potrf_inv_diag_block<true>(dsm, a.A, a.Linv, Cp, kb, a.info, tid);   // (starts with a barrier)
+      PANEL_STAMP(4 * (kb - a.p0) + 2);
       panel_publish(a.flags + 1, a.base + (kb - a.p0) + 1);
+      PANEL_STAMP(4 * (kb - a.p0) + 3);
     }
     return;
   }
@@ -590,11 +710,19 @@ __global__ __launch_bounds__(512) void chol_panel_kernel(PanelArgs a) {
     bool have_d = false;
     for (int s = blockIdx.x - 1; s < nslab; s += a.nwg) {
       const int tm = a.p0 + 1 + (s >> 1), sm = s & 1;
-      if (tm <= kb) continue;                               // this row block is (or was) the chain's
+      if (tm <= kb || (tm == kb + 1 && tm < a.p1)) continue;   // the chain's: factorized, or its look-ahead at this step
+#ifdef GPTQ_DIAG
+      const int sb = (s < 2) ? 16 + 32 * s + 8 * (kb - a.p0) : 88;   // (slabs 0 and 1 are stamped)
+#define SLAB_STAMP(i) PANEL_STAMP(sb + (s < 2 ? (i) : 0))
+#else
+#define SLAB_STAMP(i) do { } while (0)
+#endif
+      SLAB_STAMP(0);
       if (!have_d) {
         if (!panel_wait(a, a.flags + 1, a.flags + 1, val, lds_word)) return;
         have_d = true;
       }
+      SLAB_STAMP(1);
       const bool inside = tm < a.p1;                        // rows of the outer panel: their results are handed on
       float* P = a.A + ((long)tm * NB + 64 * sm) * Cp + (long)kb * NB;
       {                                                     // panel piece: P <- P inv(L_kk)^T (panel_kernel)
@@ -609,8 +737,10 @@ __global__ __launch_bounds__(512) void chol_panel_kernel(PanelArgs a) {
         tile_epilogue64(acc0, e0, 64, 64, wave >> 1, wave & 1, lane);
         tile_epilogue64(acc1, e1, 64, 64, wave >> 1, wave & 1, lane);
       }
+      SLAB_STAMP(2);
       if (inside) panel_publish(a.flags + PANEL_FLAG_SLAB0 + 2 * s, val);
       else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }   // (own P is an operand next)
+      SLAB_STAMP(3);
       const int c_last = min(a.p1 - 1, tm);
       for (int c = kb + 1; c <= c_last; ++c) {              // A[slab, c] -= P_slab P_c^T (syrk_kernel's tiles)
         const int sc = 2 * (c - a.p0 - 1);                  // the slabs of row block c
@@ -619,6 +749,7 @@ __global__ __launch_bounds__(512) void chol_panel_kernel(PanelArgs a) {
           const int* f1 = (c == tm) ? f0 : f0 + 2;          // (own piece: published above)
           if (!panel_wait(a, f0, f1, val, lds_word)) return;
         }
+        if (c == kb + 1) SLAB_STAMP(4);
         for (int sn = 0; sn < 2; ++sn) {
           if (c == tm && sn > sm) continue;                 // strictly upper quarter of a diagonal block
           Operand<float> ua{P, Cp, 1, 64, true};
@@ -629,7 +760,9 @@ __global__ __launch_bounds__(512) void chol_panel_kernel(PanelArgs a) {
           gemm_tile64<float, float, true, true>(ua, ub, 0, NB, dsm, ep);
         }
       }
+      SLAB_STAMP(5);
       if (inside) panel_publish(a.flags + PANEL_FLAG_SLAB0 + 2 * s + 1, val);
+      SLAB_STAMP(6);
     }
   }
 }
@@ -858,6 +991,11 @@ extern "C" int gptq_diag_chain64_stamps(unsigned long long* out4) {   // the las
 }
 extern "C" int gptq_diag_potrf_ablate(int v) {
   GPTQ_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(potrf_ablate), &v, sizeof(int)));
+  return GPTQ_OK;
+}
+extern "C" int gptq_diag_panel_stamps(unsigned long long* out96, int p0) {   // read the last stamps, select the next launch
+  GPTQ_CHECK_HIP(hipMemcpyFromSymbol(out96, HIP_SYMBOL(panel_stamps), sizeof(unsigned long long) * 96));
+  GPTQ_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(panel_stamp_p0), &p0, sizeof(int)));
   return GPTQ_OK;
 }
 extern "C" int gptq_diag_potrf_stamps(unsigned long long* out17) {

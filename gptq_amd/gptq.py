@@ -381,6 +381,8 @@ def _check_solved(st):
     """Wait for the solve (one sync, like torch.cuda.synchronize() at gptq.py:292); returns its `error` scalar."""
     host = st["stat"].cpu()
     bad = int(host[1:].view(torch.int32).item())
+    if bad < 0:            # chol_panel_kernel: a bounded in-kernel wait gave up (never a property of H)
+        raise _lib.GptqHipError(f"fasterquant: a workgroup hand-off of the factorization timed out (code {bad})")
     if bad:
         raise torch.linalg.LinAlgError(
             f"fasterquant: the damped Hessian is not positive-definite (pivot {bad}); cf. torch.linalg.cholesky")

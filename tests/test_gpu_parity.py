@@ -306,6 +306,21 @@ def test_chain_in_pieces_is_bit_identical_to_rfactor_upper(C, actorder):
     assert torch.equal(Hd.cpu()[valid], ref[valid])
 
 
+def test_panel_kernel_is_bit_identical_to_the_launch_per_step_chain():
+    """chol_panel_kernel (ONE launch per outer panel: the chain and the 64-row slabs as roles of a resident grid, handed
+    through flags; the chain solves its own next panel block and updates its own next diagonal tile from LDS) against
+    the three launches per 128-column step it replaces (`GPTQ_CHOL_PERSIST=0`), whole factor form, bit for bit.  Sizes:
+    640 (a second launch of one block), 1408 (11 blocks: the last outer panel has three), 2176 (17: the last has one),
+    4096; once more with 8 slab workgroups (`GPTQ_CHOL_WGS`), so that every workgroup walks several slabs per step.
+    Child processes (the mode is read once per process), each under a timeout; every in-kernel wait is bounded."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "persist_probe.py"), "640", "1408", "2176", "4096",
+                        "--wgs=160", "--wgs=8"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count("bit-identical to the launch-per-step chain: True") == 8, r.stdout[-3000:]
+
+
 def test_hinv_not_positive_definite_raises(G, hip_device):
     C = 256
     H = -torch.eye(C)

@@ -49,4 +49,9 @@ if __name__ == "__main__":
             print(f"C={C}: factor bit-identical to the launch-per-step chain: {same}"
                   + ("" if same else f" (max abs diff {(outs[0] - o).abs().max().item():.3e}, nan {int(torch.isnan(o).sum())})"), flush=True)
             bad += not same
+            if not same and C <= 2048:                     # which 128-blocks of the output differ (U-space: block (i, j) is
+                nb = C // 128                              #  the image of L-space block (nb-1-j, nb-1-i))
+                d = (outs[0] != o) | torch.isnan(o)
+                for i in range(nb):
+                    print("   ", "".join("x" if d[128 * i:128 * i + 128, 128 * j:128 * j + 128].any() else "." for j in range(nb)), flush=True)
     sys.exit(1 if bad else 0)
