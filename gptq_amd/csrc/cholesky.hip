@@ -414,6 +414,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void panel_kernel(float* __restrict__
   tile_epilogue64(acc1, Epilogue{P + 64, Cp, 1, EPI_STORE, TRI_ALL, 0.f, 0.f}, 64, 64, wave >> 1, wave & 1, lane);
 }
 
+#ifdef GPTQ_DIAG   // (measured slower as a stand-alone step, GPTQ_CHOL_SUPER: diagnostic library only)
 // Panel of a whole OUTER panel [p0, p0 + nb) for the rows below it (row blocks >= p0 + nb), one workgroup per 64 rows:
 // blocked forward substitution  P_c = (A_c - sum_{j < c} P_j L[p0 + c, p0 + j]^T) inv(L_cc)^T,  c = 0 .. nb - 1,  IN PLACE.
 // The row slabs are independent (they only read the diagonal super-block's factor and the inverses of its diagonal
@@ -453,6 +454,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void panel_super_kernel(float* __rest
     __syncthreads();                                           // P_c is visible to the waves that read it as an operand next
   }
 }
+#endif
 
 // Trailing update:  A[m][n] -= sum_{k in [k0, k0 + K)} L[m][k] L[n][k]  on the lower tiles (tm >= tn) of the block
 // columns tn in [tn0, tn1), all block rows down to nblk.  L's columns k0 .. k0 + K are final (panel solved).
@@ -920,6 +922,7 @@ static int factor_chain(float* H, int ldh, int C, float percdamp, const int32_t*
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_LDS));
   for (int p0 = 0; p0 < nblk; p0 += CSUPER) {
     const int p1 = std::min(p0 + CSUPER, nblk);
+#ifdef GPTQ_DIAG
     static const int super_env = tune_knob("GPTQ_CHOL_SUPER", 0);   // (measured: 4096 x 4096 3.82 -> 4.23 ms -- the same small launches plus one long one)
     if (super_env) {
       // the diagonal super-block [p0, p1) alone: the right-looking steps restricted to ITS rows ...
@@ -932,7 +935,9 @@ static int factor_chain(float* H, int ldh, int C, float percdamp, const int32_t*
       }
       // ... and ONE launch for the rows below it
       if (p1 < nblk) panel_super_kernel<<<2 * (nblk - p1), GEMM_THREADS, 0, s>>>(A, Linv, Cp, p0, p1 - p0, p1);
-    } else if (persist) {
+    } else
+#endif
+    if (persist) {
       if (int rc = launch_panel(A, Linv, Cp, nblk, p0, p1, info, flags, s)) return rc;
     } else {
     for (int kb = p0; kb < p1; ++kb) {

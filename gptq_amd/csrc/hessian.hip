@@ -378,6 +378,8 @@ constexpr int BHALF = BBK * 256;              // bytes of one [32 tokens][128 ch
 constexpr int BSTAGE = 4 * BHALF;             // A lo, A hi, B lo, B hi
 constexpr int BRING_DEFAULT = 4;
 
+#define BSB __builtin_amdgcn_sched_barrier(0)
+#ifdef GPTQ_DIAG   // the 32x32x16 twin of the 256 x 256 kernel (hessian16_big_kernel): diagnostic library only
 #define BTR_A(F, KK)                                         \
   do {                                                       \
     TR_READ(F[0], a0, (KK) * 4096);  TR_READ(F[1], a0, (KK) * 4096 + 1024);   \
@@ -396,7 +398,6 @@ constexpr int BRING_DEFAULT = 4;
 #define BTR_G1(F, KK) do { TR_READ(F[3], a1, (KK) * 4096 + 1024); TR_READ(F[4], a2, (KK) * 4096); TR_READ(F[5], a2, (KK) * 4096 + 1024); } while (0)
 #define BTR_G2(F, KK) do { TR_READ(F[6], a3, (KK) * 4096); TR_READ(F[7], a3, (KK) * 4096 + 1024); TR_READ(F[8], b0, (KK) * 4096); } while (0)
 #define BTR_G3(F, KK) do { TR_READ(F[9], b0, (KK) * 4096 + 1024); TR_READ(F[10], b1, (KK) * 4096); TR_READ(F[11], b1, (KK) * 4096 + 1024); } while (0)
-#define BSB __builtin_amdgcn_sched_barrier(0)
 // Eight MFMAs on the complete fragment set FC; the reads of the NEXT k-step (set FN, k-step KKN of the stage that
 // a0..b1 address) ride in the first four MFMA gaps, this wave's four LDS-DMA pieces (PIECES) in the last four.
 #define BSTEP(FC, FN, KKN, PIECES)                                                  \
@@ -424,6 +425,7 @@ constexpr int BRING_DEFAULT = 4;
     if (ABL != 1) acc[3][1] = mfma16<BF16>(fa, fb1, acc[3][1]);                     \
     BSB; if (PIECES) piece(3); BSB;                                                 \
   } while (0)
+#endif
 
 // Work decomposition (data-parallel rounds + a split last round).  T tiles over P CUs leave the last round
 // partly empty (fc2 of OPT-1.3b: 528 tiles = 2.06 rounds on 256 CUs, paid as 3).  The first floor(T/P)*P tiles
@@ -494,6 +496,7 @@ __device__ __forceinline__ void big_for_each_partial(const BigPlan& plan, int l,
   for (int v = v0; v <= v1; ++v) f(plan.left_tiles + v * BIG_MAXSEG + (l - (v * plan.chunk) / tl));
 }
 
+#ifdef GPTQ_DIAG   // (the twin: measured 2-3 % behind the 16x16x32 kernel below, kept for re-measuring only)
 // register (t, u, e) of wave `wave`, lane `lane`  <->  element of the 256 x 256 tile (C/D map of the 32x32 MFMA:
 // col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)); partial tiles are stored in register
 // order ([wave][t][u][e][lane]: every store instruction writes 256 contiguous bytes)
@@ -740,10 +743,11 @@ __global__ __launch_bounds__(64) void hessian16_big_fixup(ProbGroup pg, BigPlan 
   }
   big_epilogue_rows(H, ldh, ti, tj, wm, wn, lane, t, v, alpha, beta);
 }
+#endif   // GPTQ_DIAG
 
 // ---------------------------------------------------------------------------------------------
-// The same 256 x 256 tile on v_mfma_f32_16x16x32_{f16,bf16} -- the DEFAULT whenever a segment has an even number of
-// stages (GPTQ_HESS_SHAPE=32 selects the 32x32x16 kernel above).  Cycles per flop are those of the 32x32x16 form;
+// The 256 x 256 tile on v_mfma_f32_16x16x32_{f16,bf16} (it walks stages in pairs: tokens % 64 == 0; the diagnostic library
+// also holds a 32x32x16 twin, GPTQ_HESS_SHAPE=32).  Cycles per flop are those of the 32x32x16 form;
 // which of the two the chip clocks higher under load is an empirical matter (MI355X_MICROARCH.md "DVFS give-back"
 // item 7), so both are built on the same tile and work split: this one measures 1.5-3 % faster in the bench.
 // One k-step is a whole 32-token stage: A fragment of block t = channels 16t..16t+15 x tokens 8g..8g+7 for lane
@@ -1035,7 +1039,7 @@ static int hess_big_env() {
 
 static bool big_eligible(const HostProb& pr, int n_x, int x_dtype, int tokens) {
   if (x_dtype != GPTQ_F16 && x_dtype != GPTQ_BF16) return false;
-  if (pr.C % BT != 0 || pr.ldx % 8 != 0 || tokens % BBK != 0) return false;
+  if (pr.C % BT != 0 || pr.ldx % 8 != 0 || tokens % (2 * BBK) != 0) return false;   // (stages in pairs: 64 tokens)
   for (int i = 0; i < n_x; ++i)
     if (reinterpret_cast<uintptr_t>(pr.xs[i]) % 16 != 0) return false;
   return true;
@@ -1069,8 +1073,12 @@ static int hessian_launch_big(const HostProb* probs, int n_prob, int n_x, int x_
       }
       for (int p = np; p <= MAX_PROB; ++p) pg.tile_start[p] = total;
       const int nk_all = tokens / BBK * nx;
+#ifdef GPTQ_DIAG
       static const int shape_env = [] { const char* e = getenv("GPTQ_HESS_SHAPE"); return e ? atoi(e) : 16; }();
-      const bool shape16 = shape_env == 16 && nk_all % 2 == 0;
+      const bool shape16 = shape_env == 16;
+#else
+      constexpr bool shape16 = true;
+#endif
       BigPlan plan{total, 0, 0, 1, nullptr, 0, 0, 0};   // dp_tiles, left_tiles, workers, chunk, ws, item0, item1, head
       const int full = total / n_cu * n_cu, left = total - full;
       // cut the last round along K when it would run under 90 % full and a run still has >= 8 stages
@@ -1107,10 +1115,11 @@ static int hessian_launch_big(const HostProb* probs, int n_prob, int n_x, int x_
       const int items = plan.dp_tiles + plan.workers;
       const bool by_rounds = rounds_env != 0 && cu_limit <= 0;
       const int per_launch = by_rounds ? n_cu : items;
-      static const int bring_env = tune_knob("GPTQ_HESS_RING", BRING_DEFAULT);
 #ifdef GPTQ_DIAG   // timing-only ablation builds exist in the diagnostic library alone (python -m gptq_amd.build --diag)
+      static const int bring_env = tune_knob("GPTQ_HESS_RING", BRING_DEFAULT);
       static const int babl_env = [] { const char* e = getenv("GPTQ_HESS_ABLATE"); return e ? atoi(e) : 0; }();
 #endif
+#ifdef GPTQ_DIAG
 #define HBIG(BF, RG, AB)                                                                                      \
   do {                                                                                                        \
     const size_t lds_b = (size_t)(RG) * BSTAGE;                                                               \
@@ -1118,6 +1127,7 @@ static int hessian_launch_big(const HostProb* probs, int n_prob, int n_x, int x_
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));              \
     hessian16_big_kernel<BF, RG, AB><<<grid, 512, lds_b, s>>>(pg, plan, nx, tokens);                          \
   } while (0)
+#endif
       for (int it0 = 0; it0 < items; it0 += per_launch) {
         plan.item0 = it0;
         plan.item1 = std::min(items, it0 + per_launch);
@@ -1136,18 +1146,20 @@ static int hessian_launch_big(const HostProb* probs, int n_prob, int n_x, int x_
           }
           continue;
         }
-        if (x_dtype == GPTQ_BF16) HBIG(true, BRING_DEFAULT, 0);
 #ifdef GPTQ_DIAG
+        if (x_dtype == GPTQ_BF16) HBIG(true, BRING_DEFAULT, 0);
         else if (babl_env == 1) HBIG(false, BRING_DEFAULT, 1);
         else if (babl_env == 2) HBIG(false, BRING_DEFAULT, 2);
-#endif
         else if (bring_env == 5) HBIG(false, 5, 0);
         else HBIG(false, BRING_DEFAULT, 0);
+#endif
       }
 #undef HBIG
       if (plan.left_tiles > 0) {
         if (shape16) hessian16_big16_fixup<<<dim3(plan.left_tiles, 4), 512, 0, s>>>(pg, plan, nk_all);
+#ifdef GPTQ_DIAG
         else hessian16_big_fixup<<<dim3(plan.left_tiles, 4, 8), 64, 0, s>>>(pg, plan, nk_all);
+#endif
       }
     }
   }
