@@ -781,12 +781,8 @@ static inline int chol_persist() {
 }
 static int launch_panel(float* A, float* Linv, int Cp, int nblk, int p0, int p1, int32_t* info, int* flags,
                         hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_panel_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS));
-    attr_set = true;
-  }
+  GPTQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_panel_kernel),      // (per device: every call)
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS));
   PanelArgs pa{A, Linv, info, flags, Cp, nblk, p0, p1, 8 * (p0 / CSUPER), panel_slab_wgs(nblk, p0)};
   chol_panel_kernel<<<1 + pa.nwg, 512, PANEL_LDS, s>>>(pa);
   return GPTQ_OK;

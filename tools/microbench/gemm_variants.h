@@ -2,22 +2,119 @@
 #pragma once
 #include "../../gptq_amd/csrc/gemm2_f32.h"
 namespace gptq {
-template <bool NT>
-__global__ __launch_bounds__(GEMM_THREADS) void small_kernel(float* C, int ldc, const float* A, int lda, const float* B,
-                                                             int ldb, int M, int N, int K, int mode) {
-  __shared__ __attribute__((aligned(16))) float smem[GEMM64_LDS_FLOATS];
-  const long r0 = (long)blockIdx.y * SBM, c0 = (long)blockIdx.x * SBN;
-  Operand<float> a{A + r0 * lda, lda, 1, (int)min((long)SBM, M - r0), true};
-  Operand<float> b = NT ? Operand<float>{B + c0 * ldb, ldb, 1, (int)min((long)SBN, N - c0), true}
-                        : Operand<float>{B + c0, 1, ldb, (int)min((long)SBN, N - c0), true};
-  gemm_tile64<float, float, true, NT>(a, b, 0, K, smem, Epilogue{C + r0 * ldc + c0, ldc, 1, mode, TRI_ALL, 0.f, 0.f});
+// The product's 128 x 128 tile with parts of its stage loop removed (TIMING ONLY, wrong results) or rearranged:
+//   ABL 1: no global loads after the first stage      2: no LDS stores / barriers after the first stage      3: both
+//   ABL 4: operand registers of TWO stages (stage kt + 2 in flight while kt + 1 is stored); results exact
+template <typename TA, typename TB, bool AKC, bool BKC, int ABL>
+__device__ __forceinline__ void gemm_tile_abl(const Operand<TA>& a, const Operand<TB>& b, int k_begin, int k_end,
+                                              float* smem, const Epilogue& ep) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  float* As = smem;
+  float* Bs = smem + 2 * GBK * GLD;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  float ra[2][GST][4], rb[2][GST][4];
+  const int nk = (k_end - k_begin + GBK - 1) / GBK;
+  float old[2][2][16];
+  tile_load_old(old, ep, a.rem, b.rem, wm, wn, lane);
+  stage_load<TA, AKC>(a, k_begin, k_end, ra[0]);
+  stage_load<TB, BKC>(b, k_begin, k_end, rb[0]);
+  stage_store<AKC>(As, ra[0]);
+  stage_store<BKC>(Bs, rb[0]);
+  if (ABL == 4 && nk > 1) {
+    stage_load<TA, AKC>(a, k_begin + GBK, k_end, ra[1]);
+    stage_load<TB, BKC>(b, k_begin + GBK, k_end, rb[1]);
+  }
+  __syncthreads();
+  int cur = 0;
+#pragma unroll 2
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    const int rs = (ABL == 4) ? (kt & 1) : 0;                     // register set that receives this iteration's loads
+    if (ABL == 4) {
+      if (kt + 2 < nk) {
+        stage_load<TA, AKC>(a, k_begin + (kt + 2) * GBK, k_end, ra[rs]);
+        stage_load<TB, BKC>(b, k_begin + (kt + 2) * GBK, k_end, rb[rs]);
+      }
+    } else if (more && !(ABL & 1)) {
+      stage_load<TA, AKC>(a, k_begin + (kt + 1) * GBK, k_end, ra[0]);
+      stage_load<TB, BKC>(b, k_begin + (kt + 1) * GBK, k_end, rb[0]);
+    }
+    constexpr int LDA = LdsStride<AKC>::v, LDB = LdsStride<BKC>::v;
+    const float* Ac = As + cur * GBK * GLD + wm * 64 + (lane & 31);
+    const float* Bc = Bs + cur * GBK * GLD + wn * 64 + (lane & 31);
+    const int kq = lane >> 5;
+    float a0 = Ac[kq * LDA], a1 = Ac[kq * LDA + 32];
+    float b0 = Bc[kq * LDB], b1 = Bc[kq * LDB + 32];
+#pragma unroll
+    for (int kk = 0; kk < GBK; kk += 2) {
+      const int kn = (kk + 2 < GBK ? kk + 2 : kk) + kq;
+      const float na0 = Ac[kn * LDA], na1 = Ac[kn * LDA + 32];
+      const float nb0 = Bc[kn * LDB], nb1 = Bc[kn * LDB + 32];
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+    }
+    if (ABL == 4) {
+      if (more) {                                                  // stage kt + 1 sits in the OTHER register set
+        // (with the 2-unrolled loop kt & 1 is a compile-time constant per copy: no dynamic register indexing)
+        stage_store<AKC>(As + (cur ^ 1) * GBK * GLD, ra[rs ^ 1]);
+        stage_store<BKC>(Bs + (cur ^ 1) * GBK * GLD, rb[rs ^ 1]);
+      }
+      __syncthreads();
+      cur ^= 1;
+    } else if (!(ABL & 2)) {
+      if (more) {
+        stage_store<AKC>(As + (cur ^ 1) * GBK * GLD, ra[0]);
+        stage_store<BKC>(Bs + (cur ^ 1) * GBK * GLD, rb[0]);
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+  tile_finish(acc, old, ep, a.rem, b.rem, wm, wn, lane);
 }
-constexpr int GEMM2_VARIANTS = 1;
-inline const char* gemm2_name(int) { return "gemm_tile64 64x64"; }
-inline void gemm2_launch(int, float* C, int ldc, const float* A, int lda, const float* B, int ldb, int M, int N, int K,
+template <bool NT, int ABL>
+__global__ __launch_bounds__(GEMM_THREADS) void abl_kernel(float* C, int ldc, const float* A, int lda, const float* B,
+                                                           int ldb, int M, int N, int K, int mode) {
+  __shared__ __attribute__((aligned(16))) float smem[GEMM_LDS_FLOATS];
+  const long r0 = (long)blockIdx.y * GBM, c0 = (long)blockIdx.x * GBN;
+  Operand<float> a{A + r0 * lda, lda, 1, (int)min((long)GBM, M - r0), true};
+  Operand<float> b = NT ? Operand<float>{B + c0 * ldb, ldb, 1, (int)min((long)GBN, N - c0), true}
+                        : Operand<float>{B + c0, 1, ldb, (int)min((long)GBN, N - c0), true};
+  gemm_tile_abl<float, float, true, NT, ABL>(a, b, 0, K, smem, Epilogue{C + r0 * ldc + c0, ldc, 1, mode, TRI_ALL, 0.f, 0.f});
+}
+constexpr int GEMM2_VARIANTS = 5;
+inline const char* gemm2_name(int v) {
+  static const char* n[] = {"preload-old (product, far updates)", "ABL1 no global loads", "ABL2 no LDS stores/barriers", "ABL3 neither",
+                            "two register stages (exact)"};
+  return n[v];
+}
+template <int ABL>
+inline void abl_launch(float* C, int ldc, const float* A, int lda, const float* B, int ldb, int M, int N, int K, bool nt,
+                       int mode, hipStream_t s) {
+  dim3 grid((N + GBN - 1) / GBN, (M + GBM - 1) / GBM);
+  if (nt) abl_kernel<true, ABL><<<grid, GEMM_THREADS, 0, s>>>(C, ldc, A, lda, B, ldb, M, N, K, mode);
+  else abl_kernel<false, ABL><<<grid, GEMM_THREADS, 0, s>>>(C, ldc, A, lda, B, ldb, M, N, K, mode);
+}
+inline void gemm2_launch(int v, float* C, int ldc, const float* A, int lda, const float* B, int ldb, int M, int N, int K,
                          bool nt, int mode, hipStream_t s) {
-  dim3 grid((N + SBN - 1) / SBN, (M + SBM - 1) / SBM);
-  if (nt) small_kernel<true><<<grid, GEMM_THREADS, 0, s>>>(C, ldc, A, lda, B, ldb, M, N, K, mode);
-  else small_kernel<false><<<grid, GEMM_THREADS, 0, s>>>(C, ldc, A, lda, B, ldb, M, N, K, mode);
+  switch (v) {
+    case 0: abl_launch<0>(C, ldc, A, lda, B, ldb, M, N, K, nt, mode, s); break;
+    case 1: abl_launch<1>(C, ldc, A, lda, B, ldb, M, N, K, nt, mode, s); break;
+    case 2: abl_launch<2>(C, ldc, A, lda, B, ldb, M, N, K, nt, mode, s); break;
+    case 3: abl_launch<3>(C, ldc, A, lda, B, ldb, M, N, K, nt, mode, s); break;
+    default: abl_launch<4>(C, ldc, A, lda, B, ldb, M, N, K, nt, mode, s); break;
+  }
 }
 }  // namespace gptq
