@@ -94,10 +94,94 @@ __global__ __launch_bounds__(GEMM_THREADS) void abl_kernel(float* C, int ldc, co
                         : Operand<float>{B + c0, 1, ldb, (int)min((long)GBN, N - c0), true};
   gemm_tile_abl<float, float, true, NT, ABL>(a, b, 0, K, smem, Epilogue{C + r0 * ldc + c0, ldc, 1, mode, TRI_ALL, 0.f, 0.f});
 }
-constexpr int GEMM2_VARIANTS = 5;
+
+// The product's tile with the next stage's LDS stores INSIDE the k loop (after k-pair `AT` of 16) instead of behind it:
+// the store phase overlaps the last MFMAs of the stage and only the barrier is left between stages.  Exact.
+template <typename TA, typename TB, bool AKC, bool BKC, int AT, bool PRE>
+__device__ __forceinline__ void gemm_tile_early(const Operand<TA>& a, const Operand<TB>& b, int k_begin, int k_end,
+                                                float* smem, const Epilogue& ep) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  float* As = smem;
+  float* Bs = smem + 2 * GBK * GLD;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  float ra[GST][4], rb[GST][4];
+  const int nk = (k_end - k_begin + GBK - 1) / GBK;
+  float old[2][2][16];
+  if (PRE) tile_load_old(old, ep, a.rem, b.rem, wm, wn, lane);
+  if (nk > 0) {
+    stage_load<TA, AKC>(a, k_begin, k_end, ra);
+    stage_load<TB, BKC>(b, k_begin, k_end, rb);
+    stage_store<AKC>(As, ra);
+    stage_store<BKC>(Bs, rb);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) {
+      stage_load<TA, AKC>(a, k_begin + (kt + 1) * GBK, k_end, ra);
+      stage_load<TB, BKC>(b, k_begin + (kt + 1) * GBK, k_end, rb);
+    }
+    constexpr int LDA = LdsStride<AKC>::v, LDB = LdsStride<BKC>::v;
+    const float* Ac = As + cur * GBK * GLD + wm * 64 + (lane & 31);
+    const float* Bc = Bs + cur * GBK * GLD + wn * 64 + (lane & 31);
+    const int kq = lane >> 5;
+    float a0 = Ac[kq * LDA], a1 = Ac[kq * LDA + 32];
+    float b0 = Bc[kq * LDB], b1 = Bc[kq * LDB + 32];
+#pragma unroll
+    for (int kk = 0; kk < GBK; kk += 2) {
+      const int kn = (kk + 2 < GBK ? kk + 2 : kk) + kq;
+      const float na0 = Ac[kn * LDA], na1 = Ac[kn * LDA + 32];
+      const float nb0 = Bc[kn * LDB], nb1 = Bc[kn * LDB + 32];
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+      if (kk == 2 * AT && more) {                                  // the other buffer: nobody reads it in this stage
+        __builtin_amdgcn_sched_barrier(0);
+        stage_store<AKC>(As + (cur ^ 1) * GBK * GLD, ra);
+        stage_store<BKC>(Bs + (cur ^ 1) * GBK * GLD, rb);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  if (PRE) tile_finish(acc, old, ep, a.rem, b.rem, wm, wn, lane);
+  else tile_epilogue(acc, ep, a.rem, b.rem, wm, wn, lane);
+}
+template <bool NT, int AT, bool PRE>
+__global__ __launch_bounds__(GEMM_THREADS) void early_kernel(float* C, int ldc, const float* A, int lda, const float* B,
+                                                             int ldb, int M, int N, int K, int mode) {
+  __shared__ __attribute__((aligned(16))) float smem[GEMM_LDS_FLOATS];
+  const long r0 = (long)blockIdx.y * GBM, c0 = (long)blockIdx.x * GBN;
+  Operand<float> a{A + r0 * lda, lda, 1, (int)min((long)GBM, M - r0), true};
+  Operand<float> b = NT ? Operand<float>{B + c0 * ldb, ldb, 1, (int)min((long)GBN, N - c0), true}
+                        : Operand<float>{B + c0, 1, ldb, (int)min((long)GBN, N - c0), true};
+  gemm_tile_early<float, float, true, NT, AT, PRE>(a, b, 0, K, smem, Epilogue{C + r0 * ldc + c0, ldc, 1, mode, TRI_ALL, 0.f, 0.f});
+}
+template <int AT, bool PRE>
+inline void early_launch(float* C, int ldc, const float* A, int lda, const float* B, int ldb, int M, int N, int K, bool nt,
+                         int mode, hipStream_t s) {
+  dim3 grid((N + GBN - 1) / GBN, (M + GBM - 1) / GBM);
+  if (nt) early_kernel<true, AT, PRE><<<grid, GEMM_THREADS, 0, s>>>(C, ldc, A, lda, B, ldb, M, N, K, mode);
+  else early_kernel<false, AT, PRE><<<grid, GEMM_THREADS, 0, s>>>(C, ldc, A, lda, B, ldb, M, N, K, mode);
+}
+constexpr int GEMM2_VARIANTS = 9;
 inline const char* gemm2_name(int v) {
   static const char* n[] = {"preload-old (product, far updates)", "ABL1 no global loads", "ABL2 no LDS stores/barriers", "ABL3 neither",
-                            "two register stages (exact)"};
+                            "two register stages (exact)", "stores after k-pair 11 (exact)", "stores after k-pair 13 (exact)",
+                            "stores after k-pair 11 + preload old", "stores after k-pair 7 (exact)"};
   return n[v];
 }
 template <int ABL>
@@ -114,7 +198,11 @@ inline void gemm2_launch(int v, float* C, int ldc, const float* A, int lda, cons
     case 1: abl_launch<1>(C, ldc, A, lda, B, ldb, M, N, K, nt, mode, s); break;
     case 2: abl_launch<2>(C, ldc, A, lda, B, ldb, M, N, K, nt, mode, s); break;
     case 3: abl_launch<3>(C, ldc, A, lda, B, ldb, M, N, K, nt, mode, s); break;
-    default: abl_launch<4>(C, ldc, A, lda, B, ldb, M, N, K, nt, mode, s); break;
+    case 4: abl_launch<4>(C, ldc, A, lda, B, ldb, M, N, K, nt, mode, s); break;
+    case 5: early_launch<11, false>(C, ldc, A, lda, B, ldb, M, N, K, nt, mode, s); break;
+    case 6: early_launch<13, false>(C, ldc, A, lda, B, ldb, M, N, K, nt, mode, s); break;
+    case 7: early_launch<11, true>(C, ldc, A, lda, B, ldb, M, N, K, nt, mode, s); break;
+    default: early_launch<7, false>(C, ldc, A, lda, B, ldb, M, N, K, nt, mode, s); break;
   }
 }
 }  // namespace gptq
