@@ -315,10 +315,15 @@ def test_panel_kernel_is_bit_identical_to_the_launch_per_step_chain():
     Child processes (the mode is read once per process), each under a timeout; every in-kernel wait is bounded."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # PERSIST_STRESS: every child repeats its factorization 12 more times while a second stream keeps part of the chip busy
+    # with GEMMs of changing size, and compares every word with its first result (a stale hand-off shows up as a run
+    # that differs: hand-offs must be tested under uneven load, MI355X_MICROARCH.md)
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "persist_probe.py"), "640", "1408", "2176", "4096",
-                        "--wgs=160", "--wgs=8"], capture_output=True, text=True, timeout=900)
+                        "--wgs=160", "--wgs=8"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, PERSIST_STRESS="12"))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert r.stdout.count("bit-identical to the launch-per-step chain: True") == 8, r.stdout[-3000:]
+    assert r.stdout.count("12 runs under load, 0 differ from the first") == 12, r.stdout[-3000:]
 
 
 def test_hinv_not_positive_definite_raises(G, hip_device):

@@ -17,12 +17,31 @@ def child(C, out):
     ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
     info = torch.zeros(1, dtype=torch.int32, device="cuda")
     best = 1e9
-    for rep in range(4):
+    stress = int(os.environ.get("PERSIST_STRESS", "0"))        # that many more runs under uneven load, every word compared
+    first, diffs = None, 0
+    if stress:                                                 # a second stream keeps part of the chip busy with GEMMs of
+        side = torch.cuda.Stream()                             # changing size while the factorizations run
+        A = torch.randn(4096, 4096, device="cuda")
+    for rep in range(4 + stress):
         H = H0.clone()
+        if stress and rep >= 4:
+            with torch.cuda.stream(side):
+                for _ in range(1 + rep % 3):
+                    n = 512 * (1 + (rep * 7) % 8)
+                    torch.mm(A[:n], A[:, :n])
         torch.cuda.synchronize(); t0 = time.perf_counter()
         _lib.call("gptq_rfactor_upper", _lib.ptr(H), H.stride(0), C, 0.01, None, _lib.ptr(info), _lib.ptr(ws), nb,
                   _lib.stream(H.device))
-        torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+        if not stress or rep < 4:
+            torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+        if first is None:
+            first = H.clone()
+        elif not torch.equal(first, H):
+            diffs += 1
+    torch.cuda.synchronize()
+    if stress:
+        print(f"C={C} persist={os.environ.get('GPTQ_CHOL_PERSIST', '1')}: {stress} runs under load, {diffs} differ from the first", flush=True)
+        if diffs: sys.exit(3)
     print(f"C={C} persist={os.environ.get('GPTQ_CHOL_PERSIST', '1')} wgs={os.environ.get('GPTQ_CHOL_WGS', '-')}: "
           f"rfactor {best * 1e3:.3f} ms, info {int(info.item())}", flush=True)
     torch.save(H.cpu(), out)
