@@ -549,27 +549,29 @@ def end_to_end(dev, blocks, nsamples, hessian_defer):
                     f"{nsamples} x {SEQLEN} synthetic tokens, 4-bit --act-order --true-sequential",
            "scope": "capture + per block: 4 hooked calibration passes (one per true-sequential group) + fasterquant + "
                     "forward with quantized weights + block transfer (opt.py:686-691)"}
-    for prefetch in (False, True):
+    for key, prefetch, fbatch in (("reference_like", False, 1), ("driver_defaults", True, 1), ("forward_batch_8", True, 8)):
         model.load_state_dict(saved)
         tm = {}
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         # first run: the reference's behaviour (blocks moved on the compute stream, full hooked passes); second: this
-        # driver's defaults (copy-stream prefetch / download, hooked passes left once the group's hooks have fired)
+        # driver's defaults (copy-stream prefetch / download, hooked passes left once the group's hooks have fired);
+        # third: the defaults with 8 calibration samples per block forward (QuantArgs.forward_batch, opt-in)
         quantize_sequential(model, calib, dev, QuantArgs(wbits=4, nsamples=nsamples, act_order=True, true_sequential=True,
-                                                         hessian_defer=hessian_defer, prefetch_blocks=prefetch,
-                                                         early_exit=prefetch), timings=tm)
+                                                         hessian_defer=hessian_defer if fbatch == 1 else max(1, hessian_defer // fbatch),
+                                                         prefetch_blocks=prefetch, early_exit=prefetch, forward_batch=fbatch),
+                            timings=tm)
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
         per = lambda k: round(tm.get(k, 0.0) / blocks, 2)
-        out["driver_defaults" if prefetch else "reference_like"] = {
-            "prefetch_blocks": prefetch, "early_exit_of_hooked_passes": prefetch,
+        out[key] = {
+            "prefetch_blocks": prefetch, "early_exit_of_hooked_passes": prefetch, "forward_batch": fbatch,
             "wall_s": round(wall, 3), "s_per_block": round(wall / blocks, 3),
             "mparams_per_s": round(params / wall / 1e6, 2),
             "gpu_ms_per_block": {"forward_hooked_incl_hessian": per("forward_hooked"), "hessian": per("hessian"),
                                  "forwards_alone": round(per("forward_hooked") - per("hessian") + per("forward_final"), 2),
                                  "solve": per("solve"), "forward_final": per("forward_final"), "transfer_waited": per("transfer")}}
-        log(f"end-to-end ({'driver defaults' if prefetch else 'reference-like'}): {wall:.2f} s for {blocks} blocks")
+        log(f"end-to-end ({key}): {wall:.2f} s for {blocks} blocks")
     del model, saved
     torch.cuda.empty_cache()
     return out

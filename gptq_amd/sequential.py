@@ -48,6 +48,11 @@ class QuantArgs:
     prefetch_blocks: bool = __import__('os').environ.get('GPTQ_SEQ_PREFETCH', '1') == '1'   # upload block i + 1 / download block i - 1 on a copy stream while block i is calibrated and
                                    # solved (the reference moves blocks synchronously, opt.py:104, 219)
     early_exit: bool = __import__('os').environ.get('GPTQ_SEQ_EARLY', '1') == '1'        # leave a hooked calibration pass once every Linear of the group has fired its hook
+    forward_batch: int = int(__import__('os').environ.get('GPTQ_SEQ_BATCH', '1'))   # calibration samples per block forward.  1 = the reference (opt.py:187, 216: one
+                                   # sample per call, sized for small GPUs); more samples per call turn the block forwards -- 90 % of a block end to
+                                   # end -- from 2048-row into 16384-row GEMMs (288 GB of HBM hold them).  The hooks then see [B, S, C] inputs: the same
+                                   # running mean (gptq.py:38-65 takes any batch), but the GEMM library may pick other kernels for the larger shapes,
+                                   # so activations and H can differ from the one-by-one run in their last bits.
 
 
 class _Stop(Exception):
@@ -110,7 +115,8 @@ def _capture_layer0(model, fam, batches: Iterable[torch.Tensor], nsamples: int, 
 
 
 def _run_layer(layer, x, kwargs):
-    out = layer(x.unsqueeze(0), **kwargs)
+    """x: one sample [S, C] or a batch of samples [B, S, C] (attention mask / position tensors of the capture broadcast)."""
+    out = layer(x.unsqueeze(0) if x.dim() == 2 else x, **kwargs)
     out = out[0] if isinstance(out, (tuple, list)) else out
     return out.reshape(x.shape)
 
@@ -288,11 +294,15 @@ def _quantize_sequential(model, dataloader, dev, args, group, world, rank, timin
 
             handles = [full[n].register_forward_hook(hook(n)) for n in names]
             gmod.FLUSH_EVENTS = flush_events
+            fb = max(1, int(args.forward_batch))
             with timed("forward_hooked"):
-                for j in range(len(mine)):
+                for j in range(0, len(mine), fb):
                     seen.clear()
                     try:
-                        outs[j] = _run_layer(layer, inps[j], kwargs)
+                        if fb == 1:
+                            outs[j] = _run_layer(layer, inps[j], kwargs)
+                        else:
+                            outs[j:j + fb] = _run_layer(layer, inps[j:j + fb], kwargs)
                     except _GroupDone:
                         pass
             for h in handles:
@@ -309,9 +319,13 @@ def _quantize_sequential(model, dataloader, dev, args, group, world, rank, timin
                 quantizers[key] = solvers[n].quantizer
                 records.append(dict(name=key, error=solvers[n].error))
                 solvers[n].free()
+        fb = max(1, int(args.forward_batch))
         with timed("forward_final"):
-            for j in range(len(mine)):                        # opt.py:216-217: next block sees quantized outputs
-                outs[j] = _run_layer(layer, inps[j], kwargs)
+            for j in range(0, len(mine), fb):                 # opt.py:216-217: next block sees quantized outputs
+                if fb == 1:
+                    outs[j] = _run_layer(layer, inps[j], kwargs)
+                else:
+                    outs[j:j + fb] = _run_layer(layer, inps[j:j + fb], kwargs)
         del layer
         with timed("transfer"):
             mover.release(i)

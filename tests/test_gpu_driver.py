@@ -96,6 +96,50 @@ def test_tiny_llama_true_sequential_act_order(hip_device):
     print(f"tiny LLaMA: ppl fp16 {ppl_fp:.3f} -> gptq4 act-order true-sequential {ppl_q:.3f}")
 
 
+@pytest.mark.parametrize("family", ["llama", "opt"])
+def test_forward_batch_matches_one_sample_per_forward(hip_device, family):
+    """QuantArgs.forward_batch (several calibration samples per block forward; the reference runs one, opt.py:187, 216):
+    the hooks then see [B, S, C] inputs -- the same running-mean Hessian over the same samples.  Against the
+    one-sample-per-forward run of the same model: every Linear on its 4-bit grid, the first block's first group (whose
+    inputs are identical up to the GEMM library's choice of kernel for the larger batch) within 2 % changed weights,
+    perplexity within 2 %."""
+    import gptq_amd.gptq as gmod
+    from gptq_amd.sequential import QuantArgs, eval_ppl, llama_sequential, opt_sequential
+    gmod.VERBOSE = False
+    torch.manual_seed(0)
+    if family == "llama":
+        from transformers import LlamaConfig, LlamaForCausalLM
+        cfg = LlamaConfig(vocab_size=256, hidden_size=128, intermediate_size=352, num_hidden_layers=2,
+                          num_attention_heads=4, num_key_value_heads=4, max_position_embeddings=256)
+        model = LlamaForCausalLM(cfg).half().eval()
+        run, kw, first = llama_sequential, dict(act_order=True, true_sequential=True), "model.layers.0.self_attn.k_proj"
+    else:
+        from transformers import OPTConfig, OPTForCausalLM
+        cfg = OPTConfig(vocab_size=256, hidden_size=128, ffn_dim=512, num_hidden_layers=2, num_attention_heads=4,
+                        max_position_embeddings=256, word_embed_proj_dim=128, do_layer_norm_before=True)
+        model = OPTForCausalLM(cfg).half().eval()
+        run, kw, first = opt_sequential, dict(), "model.decoder.layers.0.self_attn.k_proj"
+    model.seqlen = 256
+    gen = torch.Generator().manual_seed(5)
+    calib = [(torch.randint(0, 256, (1, 256), generator=gen), None) for _ in range(8)]
+    test = torch.randint(0, 256, (1, 256 * 4), generator=gen)
+    saved = {k: v.clone() for k, v in model.state_dict().items()}
+    res = {}
+    for fb in (1, 4):
+        model.load_state_dict(saved)
+        q = run(model, calib, hip_device, QuantArgs(wbits=4, nsamples=8, forward_batch=fb, **kw))
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+        for n in q:
+            assert len(torch.unique(sd[n + ".weight"][0].float())) <= 16, (fb, n)
+        res[fb] = (sd, eval_ppl(model, test, hip_device), len(q))
+    assert res[1][2] == res[4][2]
+    a, b = res[1][0][first + ".weight"].float(), res[4][0][first + ".weight"].float()
+    changed = float((a != b).float().mean())
+    assert changed <= 0.02, changed
+    assert abs(res[4][1] - res[1][1]) <= 0.02 * res[1][1], (res[1][1], res[4][1])
+    print(f"forward_batch 4 vs 1 ({family}): {changed:.2e} of {first}'s weights differ, ppl {res[1][1]:.3f} vs {res[4][1]:.3f}")
+
+
 def test_opt125m_config1_end_to_end(hip_device):
     """BASELINE configs[0]: OPT-125m architecture (random init), 4-bit, nsamples = 32 synthetic samples."""
     from transformers import OPTConfig, OPTForCausalLM
