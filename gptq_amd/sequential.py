@@ -292,7 +292,20 @@ def _quantize_sequential(model, dataloader, dev, args, group, world, rank, timin
                         raise _GroupDone
                 return fn
 
-            handles = [full[n].register_forward_hook(hook(n)) for n in names]
+            def pre_hook(name):
+                # with early exit the hook sits IN FRONT of the Linear (add_batch reads the input only, gptq.py:38-65): the
+                # pass ends before the group's last Linear computes an output nobody reads
+                def fn(_, inp):
+                    solvers[name].add_batch(inp[0].data, None)
+                    seen.add(name)
+                    if len(seen) == len(names):
+                        raise _GroupDone
+                return fn
+
+            if args.early_exit and not gmod.DEBUG:
+                handles = [full[n].register_forward_pre_hook(pre_hook(n)) for n in names]
+            else:
+                handles = [full[n].register_forward_hook(hook(n)) for n in names]
             gmod.FLUSH_EVENTS = flush_events
             fb = max(1, int(args.forward_batch))
             with timed("forward_hooked"):
