@@ -554,18 +554,21 @@ def end_to_end(dev, blocks, nsamples, hessian_defer):
         tm = {}
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        # first run: the reference's behaviour (blocks moved on the compute stream, full hooked passes); second: this
-        # driver's defaults (copy-stream prefetch / download, hooked passes left once the group's hooks have fired);
+        # first run: the reference's behaviour (blocks moved on the compute stream, full hooked passes, every Linear recomputed
+        # in every pass); second: this driver's defaults (copy-stream prefetch / download, hooked passes left once the
+        # group's hooks have fired, outputs of solved Linears kept per sample);
         # third: the defaults with 8 calibration samples per block forward (QuantArgs.forward_batch, opt-in)
         quantize_sequential(model, calib, dev, QuantArgs(wbits=4, nsamples=nsamples, act_order=True, true_sequential=True,
                                                          hessian_defer=hessian_defer if fbatch == 1 else max(1, hessian_defer // fbatch),
-                                                         prefetch_blocks=prefetch, early_exit=prefetch, forward_batch=fbatch),
+                                                         prefetch_blocks=prefetch, early_exit=prefetch, forward_batch=fbatch,
+                                                         cache_outputs=prefetch),
                             timings=tm)
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
         per = lambda k: round(tm.get(k, 0.0) / blocks, 2)
         out[key] = {
-            "prefetch_blocks": prefetch, "early_exit_of_hooked_passes": prefetch, "forward_batch": fbatch,
+            "prefetch_blocks": prefetch, "early_exit_of_hooked_passes": prefetch, "cached_linear_outputs": prefetch,
+            "forward_batch": fbatch,
             "wall_s": round(wall, 3), "s_per_block": round(wall / blocks, 3),
             "mparams_per_s": round(params / wall / 1e6, 2),
             "gpu_ms_per_block": {"forward_hooked_incl_hessian": per("forward_hooked"), "hessian": per("hessian"),

@@ -48,6 +48,11 @@ class QuantArgs:
     prefetch_blocks: bool = __import__('os').environ.get('GPTQ_SEQ_PREFETCH', '1') == '1'   # upload block i + 1 / download block i - 1 on a copy stream while block i is calibrated and
                                    # solved (the reference moves blocks synchronously, opt.py:104, 219)
     early_exit: bool = __import__('os').environ.get('GPTQ_SEQ_EARLY', '1') == '1'        # leave a hooked calibration pass once every Linear of the group has fired its hook
+    cache_outputs: bool = __import__('os').environ.get('GPTQ_SEQ_CACHE', '1') == '1'      # true-sequential runs: once a group is solved, the outputs of its (now final) Linears
+                                   # are kept per calibration sample and looked up by the later hooked passes and the final pass of the block instead
+                                   # of being recomputed -- every Linear of a block then runs ONCE per sample instead of up to four times (the
+                                   # reference recomputes, llama.py:97-139); same values (same GEMM, same inputs), up to `cache_max_bytes` per block
+    cache_max_bytes: int = 96 << 30
     forward_batch: int = int(__import__('os').environ.get('GPTQ_SEQ_BATCH', '1'))   # calibration samples per block forward.  1 = the reference (opt.py:187, 216: one
                                    # sample per call, sized for small GPUs); more samples per call turn the block forwards -- 90 % of a block end to
                                    # end -- from 2048-row into 16384-row GEMMs (288 GB of HBM hold them).  The hooks then see [B, S, C] inputs: the same
@@ -272,7 +277,30 @@ def _quantize_sequential(model, dataloader, dev, args, group, world, rank, timin
             groups = [g for g in groups if g] + ([rest] if rest else [])   # never silently skipped
         else:
             groups = [list(full.keys())]
-        for names in groups:
+        # outputs of solved Linears per sample batch (cache_outputs): module -> {first sample index: output}
+        out_cache, cached_fwd, cache_bytes, cur_j = {}, {}, [0], [0]
+
+        def keep_outputs(lin):
+            orig, store = lin.forward, {}
+
+            def fwd(x, _orig=orig, _store=store):
+                hit = _store.get(cur_j[0])
+                if hit is not None:
+                    y, ver = hit
+                    if y._version != ver:                         # somebody wrote into the Linear's output in place
+                        raise RuntimeError("quantize_sequential: a cached Linear output was modified in place by the model's "
+                                           "forward; run with QuantArgs(cache_outputs=False)")
+                    return y
+                y = _orig(x)
+                if cache_bytes[0] + y.numel() * y.element_size() <= args.cache_max_bytes:
+                    _store[cur_j[0]] = (y, y._version)
+                    cache_bytes[0] += y.numel() * y.element_size()
+                return y
+            cached_fwd[lin] = orig
+            out_cache[lin] = store
+            lin.forward = fwd
+
+        for gi, names in enumerate(groups):
             solvers = {}
             for n in names:
                 solvers[n] = GPTQ(full[n])
@@ -311,6 +339,7 @@ def _quantize_sequential(model, dataloader, dev, args, group, world, rank, timin
             with timed("forward_hooked"):
                 for j in range(0, len(mine), fb):
                     seen.clear()
+                    cur_j[0] = j
                     try:
                         if fb == 1:
                             outs[j] = _run_layer(layer, inps[j], kwargs)
@@ -332,13 +361,21 @@ def _quantize_sequential(model, dataloader, dev, args, group, world, rank, timin
                 quantizers[key] = solvers[n].quantizer
                 records.append(dict(name=key, error=solvers[n].error))
                 solvers[n].free()
+            if args.cache_outputs and len(groups) > 1:          # (a single group: its Linears run once after the solve anyway)
+                for n in names:
+                    keep_outputs(full[n])
         fb = max(1, int(args.forward_batch))
         with timed("forward_final"):
             for j in range(0, len(mine), fb):                 # opt.py:216-217: next block sees quantized outputs
+                cur_j[0] = j
                 if fb == 1:
                     outs[j] = _run_layer(layer, inps[j], kwargs)
                 else:
                     outs[j:j + fb] = _run_layer(layer, inps[j:j + fb], kwargs)
+        for lin, orig in cached_fwd.items():                  # the block's Linears get their own forward back
+            del lin.forward                                   # (the instance attribute shadowed the class's method)
+        out_cache.clear()
+        cached_fwd.clear()
         del layer
         with timed("transfer"):
             mover.release(i)

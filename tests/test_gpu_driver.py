@@ -140,6 +140,34 @@ def test_forward_batch_matches_one_sample_per_forward(hip_device, family):
     print(f"forward_batch 4 vs 1 ({family}): {changed:.2e} of {first}'s weights differ, ppl {res[1][1]:.3f} vs {res[4][1]:.3f}")
 
 
+def test_cached_linear_outputs_change_nothing(hip_device):
+    """QuantArgs.cache_outputs (true-sequential runs keep the outputs of solved Linears per sample instead of recomputing
+    them in every later pass of the block): the same GEMMs on the same inputs, so the quantized model must be
+    bit-identical to the run that recomputes, with and without early exit, one and four samples per forward."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    import gptq_amd.gptq as gmod
+    from gptq_amd.sequential import QuantArgs, llama_sequential
+    gmod.VERBOSE = False
+    cfg = LlamaConfig(vocab_size=256, hidden_size=128, intermediate_size=352, num_hidden_layers=2,
+                      num_attention_heads=4, num_key_value_heads=4, max_position_embeddings=256)
+    torch.manual_seed(0)
+    model = LlamaForCausalLM(cfg).half().eval()
+    model.seqlen = 256
+    gen = torch.Generator().manual_seed(7)
+    calib = [(torch.randint(0, 256, (1, 256), generator=gen), None) for _ in range(8)]
+    saved = {k: v.clone() for k, v in model.state_dict().items()}
+    for early, fb in ((True, 1), (False, 1), (True, 4)):
+        res = []
+        for cache in (False, True):
+            model.load_state_dict(saved)
+            llama_sequential(model, calib, hip_device, QuantArgs(wbits=4, nsamples=8, act_order=True, true_sequential=True,
+                                                                 early_exit=early, forward_batch=fb, cache_outputs=cache))
+            res.append({k: v.clone() for k, v in model.state_dict().items()})
+            assert all("forward" not in m.__dict__ for m in model.modules()), "a Linear kept its caching forward"
+        for k in res[0]:
+            assert torch.equal(res[0][k], res[1][k]), (early, fb, k)
+
+
 def test_opt125m_config1_end_to_end(hip_device):
     """BASELINE configs[0]: OPT-125m architecture (random init), 4-bit, nsamples = 32 synthetic samples."""
     from transformers import OPTConfig, OPTForCausalLM
