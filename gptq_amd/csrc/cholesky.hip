@@ -538,6 +538,7 @@ constexpr int PANEL_FLAG_SLAB0 = 4;
 #ifdef GPTQ_DIAG   // s_memtime stamps of the chain (0..15) and of slabs 0 / 1 (16..47 / 48..79) in the launch p0 == panel_stamp_p0
 __device__ unsigned long long panel_stamps[96];
 __device__ int panel_stamp_p0;
+__device__ int panel_fault;   // fault injection (tests/test_gpu_parity.py): 1 = the chain never publishes its second block
 #define PANEL_STAMP(i) do { if (threadIdx.x == 0 && a.p0 == panel_stamp_p0) panel_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define PANEL_STAMP(i) do { } while (0)
@@ -699,6 +700,9 @@ __global__ __launch_bounds__(512) void chol_panel_kernel(PanelArgs a) {
       }
       potrf_inv_diag_block<true>(dsm, a.A, a.Linv, Cp, kb, a.info, tid);   // (starts with a barrier)
       PANEL_STAMP(4 * (kb - a.p0) + 2);
+#ifdef GPTQ_DIAG
+      if (panel_fault == 1 && kb == a.p0 + 1) return;            // (the chain is gone: the slabs' bounded waits must end the launch)
+#endif
       panel_publish(a.flags + 1, a.base + (kb - a.p0) + 1);
       PANEL_STAMP(4 * (kb - a.p0) + 3);
     }
@@ -992,6 +996,10 @@ extern "C" int gptq_diag_chain64_stamps(unsigned long long* out4) {   // the las
 }
 extern "C" int gptq_diag_potrf_ablate(int v) {
   GPTQ_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(potrf_ablate), &v, sizeof(int)));
+  return GPTQ_OK;
+}
+extern "C" int gptq_diag_panel_fault(int v) {
+  GPTQ_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(panel_fault), &v, sizeof(int)));
   return GPTQ_OK;
 }
 extern "C" int gptq_diag_panel_stamps(unsigned long long* out96, int p0) {   // read the last stamps, select the next launch

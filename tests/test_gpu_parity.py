@@ -326,6 +326,41 @@ def test_panel_kernel_is_bit_identical_to_the_launch_per_step_chain():
     assert r.stdout.count("12 runs under load, 0 differ from the first") == 12, r.stdout[-3000:]
 
 
+def test_panel_kernel_gives_up_instead_of_hanging():
+    """Every in-kernel wait of chol_panel_kernel is bounded.  Fault injection (diagnostic library): the chain workgroup
+    leaves after its second diagonal block without publishing it, so every slab waits in vain -- the first one to run out of polls raises
+    `abort`, all pollers leave, the launch ENDS, `info` reads -9 and the Python layer raises GptqHipError (not
+    LinAlgError: nothing is wrong with H).  Child process under a timeout."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    diag = os.path.join(root, "gptq_amd", "libgptq_hip_diag.so")
+    if not os.path.exists(diag):
+        pytest.skip("diagnostic library not built (python -m gptq_amd.build --diag)")
+    code = """
+import ctypes, sys, time, torch
+sys.path.insert(0, %r)
+import gptq_amd
+from gptq_amd import _lib
+lib = _lib.load()
+lib.gptq_diag_panel_fault.argtypes = [ctypes.c_int]
+assert lib.gptq_diag_panel_fault(1) == 0
+C = 1024
+X = torch.randn(2 * C, C, device="cuda")
+lin = torch.nn.Linear(C, 256, bias=False, device="cuda", dtype=torch.float16)
+g = gptq_amd.GPTQ(lin); g.quantizer = gptq_amd.Quantizer(); g.quantizer.configure(4, perchannel=True, sym=False)
+g.H = (X.t() @ X) / C; g.nsamples = 2
+t0 = time.time()
+try:
+    g.fasterquant()
+    print("NO ERROR")
+except _lib.GptqHipError as e:
+    print("GAVE UP after %%.1f s: %%s" %% (time.time() - t0, e))
+""" % root
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GPTQ_HIP_LIB=diag), capture_output=True,
+                       text=True, timeout=120)
+    assert "GAVE UP" in r.stdout and "timed out" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_hinv_not_positive_definite_raises(G, hip_device):
     C = 256
     H = -torch.eye(C)
