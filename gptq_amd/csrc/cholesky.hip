@@ -509,15 +509,19 @@ static inline int syrk_tiles(int nblk, int tn0, int tn1) {       // sum_{tn in [
 // ONE launch per outer panel [p0, p1) of the factorization (round 3) instead of three per 128-column step: the diagonal
 // chain, the panel solves of all rows below and the rank-128 updates inside the outer panel are ROLES of one resident
 // grid, handed from role to role through flags in device memory.
-//   workgroup 0 ("chain"): for kb = p0 .. p1 - 1: wait until the two 64-row slabs of row block kb carry the updates of
-//     step kb - 1, factorize + invert the diagonal block (potrf_inv_diag_block), publish D = step kb.
+//   workgroup 0 ("chain"): for kb = p0 .. p1 - 1: factorize + invert the diagonal block (potrf_inv_diag_block), publish
+//     D = step kb; in front of every block but the first, its OWN look-ahead from the inverse it still holds in LDS: the
+//     panel block P = A[kb, kb-1] inv(L)^T of its next row block and the update of its next diagonal tile
+//     D = A[kb, kb] - P P^T (it waits only until the two slabs of row block kb have applied step kb - 2, which they did
+//     one diagonal block ago), and it publishes P as those two slabs' panel pieces.
 //   workgroup 1 + j ("slabs" j, j + nwg, ...; slab s = 64 rows: row block p0 + 1 + s / 2, half s & 1): for every step kb
-//     above its rows: wait for D, solve its 64 x 128 piece of the panel in place (panel_kernel's product), publish it if
-//     its rows lie inside the outer panel (their pieces are the B operands of everybody's updates), then apply the
-//     rank-128 update to its rows of the block columns kb + 1 .. p1 - 1 (syrk_kernel's 64 x 64 tiles) as soon as the
-//     slabs of those block columns have published, and publish "done" (the chain's go-ahead for its next block).
-// What this buys is look-ahead without a stream hand-off per step: the chain waits for ONE row block's panel solve and
-// diagonal-tile update (two of the up to 170 slabs), the other slabs work underneath the next diagonal block.
+//     at least two row blocks above its rows (row block kb + 1 is the chain's at step kb): wait for D, solve its 64 x 128
+//     piece of the panel in place (panel_kernel's product), publish it if its rows lie inside the outer panel (their
+//     pieces are the B operands of everybody's updates), then apply the rank-128 update to its rows of the block columns
+//     kb + 1 .. p1 - 1 (syrk_kernel's 64 x 64 tiles) as soon as the pieces of those block columns are published, and
+//     publish "done" (the chain's go-ahead two steps later).
+// What this buys is look-ahead without any hand-off on the critical path: between two diagonal blocks the chain does
+// two small products on its own compute unit, everything else happens underneath the next diagonal block.
 // Same device functions, same ascending k order as the separate launches: the factor is bit-identical.
 // Hand-offs (MI355X_MICROARCH.md, inter-workgroup visibility): handed-off bytes leave with write-through `sc1` stores,
 // every storing wave drains vmcnt, workgroup barrier, one relaxed agent-scope flag store; the consumer polls relaxed
