@@ -385,7 +385,8 @@ def main():
         gmod.HESSIAN_DEFER, gmod.LAZY_HESSIANS = 1, False
         b3 = Block(args.workload, args, dev, 0, 1)
         el = b3.run(1, args.also_steps, barrier)
-        out["default_mode"] = {"hessian_defer": 1, "lazy_hessians": False, "steps": args.also_steps,
+        out["default_mode"] = {"hessian_defer": 1, "lazy_hessians": False, "stage_inputs": int(gmod.STAGE_INPUTS),
+                               "steps": args.also_steps,
                                "ms_per_step": round(el / args.also_steps * 1e3, 3),
                                "value": round(b3.params / (el / args.also_steps) / 1e6, 2), "unit": "Mparams/s",
                                "phases": {k: round(v / args.also_steps, 3) for k, v in b3.phase_ms.items()}}

@@ -40,6 +40,15 @@ TRACK_INPUT_MEAN = False
 # fresh tensors).  What can be checked is checked: an input whose torch version counter moved, or whose storage is
 # handed in again while still pending, raises instead of silently corrupting H.
 HESSIAN_DEFER = 1
+# STAGE_INPUTS (HESSIAN_DEFER = 1 only): add_batch COPIES its input into a buffer the library owns (enqueued on the
+# current stream before the hook returns, so the caller may still overwrite or recycle the activation right away) and
+# folds the copies of up to STAGE_INPUTS calls into H with ONE launch -- the batched launch's efficiency (a single
+# 2048-token sample per launch runs the 256 x 256 kernel with K = 2048: 119 ms of Hessian time per Llama-7B block
+# against 37 at 16 samples per launch) without keeping a reference to anything of the caller's.  The price is one pass
+# over the input (2 x 45 MB at C = 11008: 25 us per sample) and 16 staged samples per object (0.27-0.72 GB).  What a caller
+# can observe is unchanged: `nsamples` moves at once, `.H`, `fasterquant` and `free` fold what is staged first.
+# 1 = off: one launch per call, like round 2's default.
+STAGE_INPUTS = int(__import__('os').environ.get('GPTQ_STAGE_INPUTS', '16'))
 
 
 # The reference's free() ends with torch.cuda.empty_cache() (gptq.py:313-318), which hands every cached block
@@ -578,10 +587,14 @@ class GPTQ:
                               or self._pending[0][0].stride(0) != x.stride(0)):
             flush_pending()
         defer = max(1, int(HESSIAN_DEFER))
+        staged = defer <= 1 and int(STAGE_INPUTS) > 1
+        if staged:                       # an owned copy (STAGE_INPUTS): nothing of the caller's is referenced after the hook
+            x = x.clone(memory_format=torch.contiguous_format)
+            defer = int(STAGE_INPUTS)
         if defer > 1 and len(self._pending) >= defer:
             # this object is about to exceed the batch: its lock-step peers (the other Linears hooked in
             # the same forward passes) hold exactly as many inputs, so everything goes out grouped by shape
-            if not LAZY_HESSIANS:
+            if staged or not LAZY_HESSIANS:
                 flush_pending()
             elif 2 * self.columns >= _widest_live():          # one of the widest Linears being calibrated
                 flush_pending(heavy_only=True)

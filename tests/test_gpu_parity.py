@@ -1386,8 +1386,9 @@ def test_hessians_of_different_widths_in_one_call(G):
 
 
 def test_add_batch_consumes_its_input_inside_the_call(G, O, hip_device):
-    """HESSIAN_DEFER = 1 (default): like gptq.py:59-65 the update for `inp` is enqueued before add_batch returns, so a
-    caller may refill ONE staging buffer per sample.  With deferral the same pattern is refused loudly."""
+    """HESSIAN_DEFER = 1 (default): like gptq.py:59-65 `inp` is consumed before add_batch returns -- copied into a buffer of
+    the library's (STAGE_INPUTS, the default) or folded into H at once (STAGE_INPUTS = 1) -- so a caller may refill ONE
+    staging buffer per sample.  With deferral (references, no copies) the same pattern is refused loudly."""
     gm = G.gptq
     assert gm.HESSIAN_DEFER == 1
     gen = torch.Generator().manual_seed(3)
@@ -1397,13 +1398,24 @@ def test_add_batch_consumes_its_input_inside_the_call(G, O, hip_device):
     n = 0
     for x in xs:
         n = O.hessian_add_batch(Href, n, x)
-    gp = G.GPTQ(make_linear(torch.zeros(4, C, device=hip_device)))
     buf = torch.empty(1, S, C, device=hip_device, dtype=torch.float16)
-    for x in xs:
-        buf.copy_(x)                      # the previous sample is overwritten right after its hook returned
-        gp.add_batch(buf, None)
-        assert not gp._pending
-    assert relfro(gp.H.cpu(), Href) <= 1e-6
+    old_stage = gm.STAGE_INPUTS
+    try:
+        for stage in (old_stage, 1):      # staged copies (the default) / one launch per call
+            gm.STAGE_INPUTS = stage
+            gp = G.GPTQ(make_linear(torch.zeros(4, C, device=hip_device)))
+            for x in xs:
+                buf.copy_(x)              # the previous sample is overwritten right after its hook returned
+                gp.add_batch(buf, None)
+                if stage > 1:             # what is still to be folded is the library's own copy, never the caller's buffer
+                    assert all(t.data_ptr() != buf.data_ptr() for t, _, _ in gp._pending)
+                else:
+                    assert not gp._pending
+            assert gp.nsamples == len(xs)
+            assert relfro(gp.H.cpu(), Href) <= 1e-6
+            assert not gp._pending
+    finally:
+        gm.STAGE_INPUTS = old_stage
     old = gm.HESSIAN_DEFER
     try:
         gm.HESSIAN_DEFER = 4
