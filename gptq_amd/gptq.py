@@ -314,6 +314,9 @@ def fasterquant_many(solvers, blocksize=128, percdamp=.01, groupsize=-1, actorde
                 with torch.cuda.stream(st):
                     own = owner(g)
                     if own._pending:                 # the caller's-stream units fold their own, at full width ...
+                        if st is not cur:            # (inputs / staged copies were allocated on the caller's stream: their
+                            for x, _, _ in own._pending:      # memory must not be handed out again before this lane has read them)
+                                x.record_stream(st)
                         _launch_flush([own])
                         if k == 0 and late and late_done is None and want > 1:
                             wide_done = torch.cuda.Event()      # ... and the late updates start after them
