@@ -174,7 +174,8 @@ class Block:
             solvers = []
             for lin in g:
                 n, r, c, _ = lin
-                m = torch.nn.Linear(c, r, bias=False, device=dev, dtype=torch.float16)
+                # (no random init of a weight that is replaced at once: 0.24 ms of RNG kernels per step)
+                m = torch.nn.utils.skip_init(torch.nn.Linear, c, r, bias=False, device=dev, dtype=torch.float16)
                 m.weight.data = self.weights[n].clone()
                 s = G.GPTQ(m)
                 s.quantizer = G.Quantizer()
