@@ -311,7 +311,7 @@ def test_panel_kernel_is_bit_identical_to_the_launch_per_step_chain():
     through flags; the chain solves its own next panel block and updates its own next diagonal tile from LDS) against
     the three launches per 128-column step it replaces (`GPTQ_CHOL_PERSIST=0`), whole factor form, bit for bit.  Sizes:
     640 (a second launch of one block), 1408 (11 blocks: the last outer panel has three), 2176 (17: the last has one),
-    4096; once more with 8 slab workgroups (`GPTQ_CHOL_WGS`), so that every workgroup walks several slabs per step.
+    4096, 11008 (the widest Linear of the headline block: 170 slabs on 160 workgroups); once more with 8 slab workgroups (`GPTQ_CHOL_WGS`), so that every workgroup walks several slabs per step.
     Child processes (the mode is read once per process), each under a timeout; every in-kernel wait is bounded."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -319,11 +319,11 @@ def test_panel_kernel_is_bit_identical_to_the_launch_per_step_chain():
     # with GEMMs of changing size, and compares every word with its first result (a stale hand-off shows up as a run
     # that differs: hand-offs must be tested under uneven load, MI355X_MICROARCH.md)
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "persist_probe.py"), "640", "1408", "2176", "4096",
-                        "--wgs=160", "--wgs=8"], capture_output=True, text=True, timeout=900,
+                        "11008", "--wgs=160", "--wgs=8"], capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, PERSIST_STRESS="12"))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert r.stdout.count("bit-identical to the launch-per-step chain: True") == 8, r.stdout[-3000:]
-    assert r.stdout.count("12 runs under load, 0 differ from the first") == 12, r.stdout[-3000:]
+    assert r.stdout.count("bit-identical to the launch-per-step chain: True") == 10, r.stdout[-3000:]
+    assert r.stdout.count("12 runs under load, 0 differ from the first") == 15, r.stdout[-3000:]
 
 
 def test_panel_kernel_gives_up_instead_of_hanging():
